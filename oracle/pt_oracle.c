@@ -1,0 +1,611 @@
+/*
+ * pt_oracle.c — TEST INFRASTRUCTURE ONLY (see pt_oracle.h). Scalar C99 restatement of docs/SPEC.md.
+ *
+ * §1 (pto_reference_sphere) follows the reference shader
+ *   /root/reference/RayTracing/Assets/Shaders/Source/Ray/Test.hlsl:1-40
+ * in the instruction order of the committed Test.spirv; every line cites the HLSL line it restates.
+ * §2-§6 (pto_render and helpers) restate this repo's own spec — the reference has none of it
+ * (SURVEY.md §0): PARITY UNPINNED against the reference for those parts.
+ *
+ * Build: gcc -std=gnu99 -O2 -ffp-contract=off -fno-math-errno -mfma -fopenmp (oracle/Makefile).
+ * Written independently of pathtracing_amd/csrc; the two share no source.
+ */
+#include "pt_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float lo[3]; int32_t ref; float hi[3]; uint32_t aux; } slot_t;                              /* 32 B */
+typedef struct { float v0[3]; uint32_t id; float e1[3]; uint32_t mat; float e2[3]; uint32_t pad; } tri48_t; /* 48 B */
+
+static inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static inline float min_(float a, float b) { return a < b ? a : b; }
+static inline float max_(float a, float b) { return a > b ? a : b; }
+static inline v3 mk(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline float dot3(v3 a, v3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+static inline v3 cross3(v3 a, v3 b)
+{
+    return mk(fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x)));
+}
+static inline v3 norm3(v3 v)
+{
+    float s = 1.0f / sqrtf(dot3(v, v));
+    return mk(v.x * s, v.y * s, v.z * s);
+}
+static inline v3 madd3(float t, v3 d, v3 o) { return mk(fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z)); }
+static inline v3 sub3(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+static inline float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* ------------------------------------------------------------------ SPEC §1: the reference kernel */
+
+uint8_t pto_unorm8(float c)
+{
+    /* R8G8B8A8Unorm store, Renderer.cs:124: clamp to [0,1], scale, round to nearest */
+    if (!(c > 0.0f)) return 0; /* also NaN */
+    if (c >= 1.0f) return 255;
+    return (uint8_t)floorf(c * 255.0f + 0.5f);
+}
+
+int pto_reference_sphere(uint32_t w, uint32_t h, float *rgba, uint8_t *rgba8)
+{
+    const float inv1080 = bits2f(0x3a72b9d6u); /* OpConstant %26 = f32(1/1080): Test.hlsl:6-7 `id.xy / resolution` */
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            float uvx = ((float)x * inv1080) * 2.0f - 1.0f; /* Test.hlsl:7 */
+            float uvy = ((float)y * inv1080) * 2.0f - 1.0f;
+            float vx = uvx, vy = uvy, vz = -1.0f;           /* Test.hlsl:10 float3(uv,-1) */
+            float l = sqrtf(vx * vx + vy * vy + vz * vz);
+            float dx = vx / l, dy = vy / l, dz = vz / l;    /* normalize */
+            float a = dx * dx + dy * dy + dz * dz;          /* Test.hlsl:17 */
+            float b = 2.0f * dz;                            /* Test.hlsl:16,18: oc=(0,0,1) */
+            float disc = fma_(b, b, a * -3.0f);             /* Test.hlsl:19,21: c = 1-0.25 */
+            float c4[4];
+            if (disc > 0.0f) {                              /* Test.hlsl:24 */
+                float t = fma_(dz, -2.0f, -sqrtf(disc)) / (2.0f * a); /* Test.hlsl:27 */
+                float px = 0.0f + dx * t, py = 0.0f + dy * t, pz = 1.0f + dz * t; /* Test.hlsl:28 */
+                float pl = sqrtf(px * px + py * py + pz * pz);
+                float nx = px / pl, ny = py / pl, nz = pz / pl; /* Test.hlsl:29 (centre = 0) */
+                c4[0] = nx * 0.5f + 0.5f; c4[1] = ny * 0.5f + 0.5f; c4[2] = nz * 0.5f + 0.5f; c4[3] = 1.0f; /* :31 */
+            } else {
+                c4[0] = uvx; c4[1] = uvy; c4[2] = 0.0f; c4[3] = 1.0f; /* Test.hlsl:36 */
+            }
+            size_t i = ((size_t)y * w + x) * 4;             /* Test.hlsl:39 */
+            if (rgba) memcpy(rgba + i, c4, 16);
+            if (rgba8) for (int k = 0; k < 4; ++k) rgba8[i + k] = pto_unorm8(c4[k]);
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ SPEC §2: RNG */
+
+uint32_t pto_pcg(uint32_t x)
+{
+    uint32_t s = x * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (w >> 22) ^ w;
+}
+uint32_t pto_path_key(uint32_t seed, uint32_t pixel, uint32_t sample) { return pto_pcg(pto_pcg(pto_pcg(seed) + pixel) + sample); }
+float pto_u01(uint32_t key, uint32_t dim) { return (float)(pto_pcg(key + dim * 0x9E3779B9u) >> 8) * 5.9604644775390625e-8f; }
+
+void pto_sincos2pi(float u, float *so, float *co)
+{
+    float x = u * 4.0f;
+    int q = (int)x;
+    float f = x - (float)q;
+    float a = (f - 0.5f) * 1.57079637f;
+    float a2 = a * a;
+    float s = a * fma_(a2, fma_(a2, fma_(a2, fma_(a2, 2.75573192e-6f, -1.98412698e-4f), 8.33333377e-3f), -1.66666672e-1f), 1.0f);
+    float c = fma_(a2, fma_(a2, fma_(a2, fma_(a2, 2.48015876e-5f, -1.38888892e-3f), 4.16666679e-2f), -0.5f), 1.0f);
+    float S = (s + c) * 0.707106769f, C = (c - s) * 0.707106769f;
+    switch (q & 3) {
+    case 0: *so = S; *co = C; break;
+    case 1: *so = C; *co = -S; break;
+    case 2: *so = -S; *co = -C; break;
+    default: *so = -C; *co = S; break;
+    }
+}
+
+/* ------------------------------------------------------------------ SPEC §3: camera */
+
+void pto_camera_ray(const pto_camera *c, uint32_t x, uint32_t y, uint32_t key, float o[3], float d[3])
+{
+    float jx = c->jitter ? pto_u01(key, 0) : 0.5f;
+    float jy = c->jitter ? pto_u01(key, 1) : 0.5f;
+    float sx = ((float)x + jx) * c->scale - c->cx;
+    float sy = ((float)y + jy) * c->scale - c->cy;
+    v3 v = mk(fma_(sy, c->up[0], fma_(sx, c->right[0], c->forward[0])),
+              fma_(sy, c->up[1], fma_(sx, c->right[1], c->forward[1])),
+              fma_(sy, c->up[2], fma_(sx, c->right[2], c->forward[2])));
+    v = norm3(v);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z;
+    o[0] = c->origin[0]; o[1] = c->origin[1]; o[2] = c->origin[2];
+}
+
+/* ------------------------------------------------------------------ SPEC §4: intersection */
+
+typedef struct { v3 v0, e1, e2; uint32_t id, mat; } trirec;
+typedef struct { float t; uint32_t id; int is_sphere; trirec tri; uint32_t sph; } hit_t;
+
+static inline trirec tri_from_raw(const pto_scene *s, uint32_t i)
+{
+    const float *p = s->tri_verts + (size_t)i * 9;
+    trirec r;
+    r.v0 = ld3(p);
+    r.e1 = sub3(ld3(p + 3), r.v0);
+    r.e2 = sub3(ld3(p + 6), r.v0);
+    r.id = i;
+    r.mat = s->tri_mat ? s->tri_mat[i] : 0;
+    return r;
+}
+static inline trirec tri_from_blob(const tri48_t *b)
+{
+    trirec r;
+    r.v0 = ld3(b->v0); r.e1 = ld3(b->e1); r.e2 = ld3(b->e2); r.id = b->id; r.mat = b->mat;
+    return r;
+}
+
+static inline void test_tri(const trirec *tr, v3 o, v3 d, hit_t *h)
+{
+    v3 p = cross3(d, tr->e2);
+    float det = dot3(tr->e1, p);
+    if (det == 0.0f) return;
+    float inv_det = 1.0f / det;
+    v3 tv = sub3(o, tr->v0);
+    float u = dot3(tv, p) * inv_det;
+    if (!(u >= 0.0f && u <= 1.0f)) return;
+    v3 q = cross3(tv, tr->e1);
+    float v = dot3(d, q) * inv_det;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return;
+    float t = dot3(tr->e2, q) * inv_det;
+    if (!(t > 0.0f)) return;
+    if (t < h->t || (t == h->t && tr->id < h->id)) { h->t = t; h->id = tr->id; h->is_sphere = 0; h->tri = *tr; }
+}
+
+static inline void test_sphere(const pto_scene *s, uint32_t j, v3 o, v3 d, hit_t *h)
+{
+    const float *sp = s->spheres + (size_t)j * 4;
+    v3 oc = sub3(o, ld3(sp));
+    float b = dot3(oc, d);
+    float cc = dot3(oc, oc) - sp[3] * sp[3];
+    float disc = fma_(b, b, -cc);
+    if (!(disc > 0.0f)) return;
+    float sq = sqrtf(disc);
+    float t0 = -b - sq, t1 = -b + sq;
+    float t = (t0 > 0.0f) ? t0 : t1;
+    if (!(t > 0.0f)) return;
+    uint32_t id = s->n_tris + j;
+    if (t < h->t || (t == h->t && id < h->id)) { h->t = t; h->id = id; h->is_sphere = 1; h->sph = j; }
+}
+
+static void closest_hit(const pto_scene *s, v3 o, v3 d, hit_t *h, pto_stats *st)
+{
+    h->t = INFINITY; h->id = PTO_MISS; h->is_sphere = 0; h->sph = 0;
+    for (uint32_t j = 0; j < s->n_spheres; ++j) { test_sphere(s, j, o, d, h); st->sphere_tests++; }
+    if (s->n_tris == 0) return;
+    if (!s->nodes) { /* brute force */
+        for (uint32_t i = 0; i < s->n_tris; ++i) { trirec tr = tri_from_raw(s, i); test_tri(&tr, o, d, h); st->tri_tests++; }
+        return;
+    }
+    float dd[3] = { d.x, d.y, d.z }, oo[3] = { o.x, o.y, o.z }, inv[3], noi[3];
+    for (int k = 0; k < 3; ++k) {
+        float dk = (fabsf(dd[k]) < 1e-20f) ? copysignf(1e-20f, dd[k]) : dd[k];
+        inv[k] = 1.0f / dk;
+        noi[k] = -(oo[k] * inv[k]);
+    }
+    const uint32_t N = s->bvh_width;
+    const slot_t *nodes = (const slot_t *)s->nodes;
+    const tri48_t *tris = (const tri48_t *)s->tris48;
+    int32_t stack[512];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        int32_t ref = stack[--sp];
+        if (ref >= 0) {
+            const slot_t *nd = nodes + (size_t)ref * N;
+            st->node_visits++;
+            uint32_t keys[8]; int32_t refs[8]; int nh = 0;
+            for (uint32_t c = 0; c < N; ++c) {
+                if (nd[c].ref == PTO_BVH_EMPTY) continue;
+                float tax = fma_(nd[c].lo[0], inv[0], noi[0]), tbx = fma_(nd[c].hi[0], inv[0], noi[0]);
+                float tay = fma_(nd[c].lo[1], inv[1], noi[1]), tby = fma_(nd[c].hi[1], inv[1], noi[1]);
+                float taz = fma_(nd[c].lo[2], inv[2], noi[2]), tbz = fma_(nd[c].hi[2], inv[2], noi[2]);
+                float tn = max_(max_(min_(tax, tbx), min_(tay, tby)), max_(min_(taz, tbz), 0.0f));
+                float tf = min_(min_(max_(tax, tbx), max_(tay, tby)), min_(max_(taz, tbz), h->t)) * 1.0000004f;
+                if (tn <= tf) { keys[nh] = (f2bits(tn) & ~3u) | c; refs[nh] = nd[c].ref; nh++; }
+            }
+            /* push in descending key order */
+            for (int i = 1; i < nh; ++i) {
+                uint32_t k = keys[i]; int32_t r = refs[i]; int j = i - 1;
+                while (j >= 0 && keys[j] < k) { keys[j + 1] = keys[j]; refs[j + 1] = refs[j]; --j; }
+                keys[j + 1] = k; refs[j + 1] = r;
+            }
+            for (int i = 0; i < nh; ++i) { if (sp >= 512) abort(); stack[sp++] = refs[i]; }
+        } else {
+            uint32_t enc = (uint32_t)~ref, first = enc >> 3, cnt = (enc & 7u) + 1u;
+            for (uint32_t j = 0; j < cnt; ++j) { trirec tr = tri_from_blob(tris + first + j); test_tri(&tr, o, d, h); st->tri_tests++; }
+        }
+    }
+}
+
+uint32_t pto_closest(const pto_scene *s, const float o[3], const float d[3], float *t, pto_stats *st)
+{
+    pto_stats loc; memset(&loc, 0, sizeof loc);
+    hit_t h;
+    closest_hit(s, ld3(o), ld3(d), &h, st ? st : &loc);
+    if (t) *t = h.t;
+    return h.id;
+}
+
+/* ------------------------------------------------------------------ SPEC §5: BSDFs and path loop */
+
+static inline void basis(v3 n, v3 *tx, v3 *ty)
+{
+    float sg = copysignf(1.0f, n.z);
+    float a = -1.0f / (sg + n.z);
+    float b = n.x * n.y * a;
+    *tx = mk(fma_(sg * n.x, n.x * a, 1.0f), sg * b, -(sg * n.x));
+    *ty = mk(b, fma_(n.y, n.y * a, sg), -n.y);
+}
+static inline v3 to_world(v3 l, v3 tx, v3 ty, v3 n)
+{
+    v3 w = mk(fma_(l.z, n.x, fma_(l.y, ty.x, l.x * tx.x)),
+              fma_(l.z, n.y, fma_(l.y, ty.y, l.x * tx.y)),
+              fma_(l.z, n.z, fma_(l.y, ty.z, l.x * tx.z)));
+    return norm3(w);
+}
+static inline void schlick(const float alb[3], float cosF, float F[3])
+{
+    float m = 1.0f - cosF, m2 = m * m, m5 = m2 * m2 * m;
+    for (int k = 0; k < 3; ++k) F[k] = fma_(1.0f - alb[k], m5, alb[k]);
+}
+static inline v3 reflect_about(v3 d, v3 n, float cosi)
+{
+    float c2 = 2.0f * cosi;
+    return norm3(mk(fma_(c2, n.x, d.x), fma_(c2, n.y, d.y), fma_(c2, n.z, d.z)));
+}
+
+int pto_bsdf_sample(const pto_material *m, const float dv[3], const float nv[3], int front,
+                    float u1, float u2, float u3, float wi_o[3], float W[3], float *side)
+{
+    v3 d = ld3(dv), n = ld3(nv), wi;
+    float cosi = min_(max_(-dot3(d, n), 0.0f), 1.0f);
+    *side = 1.0f;
+    if (m->kind == PTO_LAMBERT) {
+        v3 tx, ty; basis(n, &tx, &ty);
+        float r = sqrtf(u1), sn, cs;
+        pto_sincos2pi(u2, &sn, &cs);
+        v3 l = mk(r * cs, r * sn, sqrtf(max_(0.0f, 1.0f - u1)));
+        wi = to_world(l, tx, ty, n);
+        W[0] = m->albedo[0]; W[1] = m->albedo[1]; W[2] = m->albedo[2];
+    } else if (m->kind == PTO_METAL) {
+        float al = m->roughness;
+        if (al == 0.0f) {
+            wi = reflect_about(d, n, cosi);
+            schlick(m->albedo, cosi, W);
+        } else {
+            v3 tx, ty; basis(n, &tx, &ty);
+            v3 wo = mk(-d.x, -d.y, -d.z);
+            v3 wl = mk(dot3(wo, tx), dot3(wo, ty), dot3(wo, n));
+            v3 Vh = norm3(mk(al * wl.x, al * wl.y, wl.z));
+            float lensq = fma_(Vh.y, Vh.y, Vh.x * Vh.x);
+            v3 T1;
+            if (lensq > 0.0f) { float il = 1.0f / sqrtf(lensq); T1 = mk(-Vh.y * il, Vh.x * il, 0.0f); }
+            else T1 = mk(1.0f, 0.0f, 0.0f);
+            v3 T2 = cross3(Vh, T1);
+            float r = sqrtf(u1), sn, cs;
+            pto_sincos2pi(u2, &sn, &cs);
+            float t1 = r * cs, t2 = r * sn, s5 = 0.5f * (1.0f + Vh.z);
+            t2 = fma_(s5, t2, (1.0f - s5) * sqrtf(max_(0.0f, 1.0f - t1 * t1)));
+            float nz = sqrtf(max_(0.0f, 1.0f - t1 * t1 - t2 * t2));
+            v3 Nh = mk(fma_(nz, Vh.x, fma_(t2, T2.x, t1 * T1.x)),
+                       fma_(nz, Vh.y, fma_(t2, T2.y, t1 * T1.y)),
+                       fma_(nz, Vh.z, fma_(t2, T2.z, t1 * T1.z)));
+            v3 hh = norm3(mk(al * Nh.x, al * Nh.y, max_(0.0f, Nh.z)));
+            float dh = dot3(wl, hh);
+            float cosF = min_(max_(dh, 0.0f), 1.0f);
+            float c2 = 2.0f * dh;
+            v3 wil = mk(fma_(c2, hh.x, -wl.x), fma_(c2, hh.y, -wl.y), fma_(c2, hh.z, -wl.z));
+            if (!(wil.z > 0.0f)) return 0;
+            float wz = wil.z;
+            float G1 = 2.0f * wz / (wz + sqrtf(fma_(al * al, 1.0f - wz * wz, wz * wz)));
+            float F[3]; schlick(m->albedo, cosF, F);
+            W[0] = F[0] * G1; W[1] = F[1] * G1; W[2] = F[2] * G1;
+            wi = to_world(wil, tx, ty, n);
+        }
+    } else { /* PTO_DIELECTRIC */
+        float ior = m->ior;
+        float eta = front ? 1.0f / ior : ior;
+        float sin2t = eta * eta * (1.0f - cosi * cosi);
+        int refl = 1;
+        float cost = 0.0f;
+        if (!(sin2t >= 1.0f)) {
+            cost = sqrtf(1.0f - sin2t);
+            float ni = front ? 1.0f : ior, nt = front ? ior : 1.0f;
+            float rp = (nt * cosi - ni * cost) / (nt * cosi + ni * cost);
+            float rs = (ni * cosi - nt * cost) / (ni * cosi + nt * cost);
+            float F = 0.5f * (rp * rp + rs * rs);
+            refl = (u3 < F);
+        }
+        if (refl) wi = reflect_about(d, n, cosi);
+        else {
+            float k = fma_(eta, cosi, -cost);
+            wi = norm3(mk(fma_(k, n.x, eta * d.x), fma_(k, n.y, eta * d.y), fma_(k, n.z, eta * d.z)));
+            *side = -1.0f;
+        }
+        W[0] = m->albedo[0]; W[1] = m->albedo[1]; W[2] = m->albedo[2];
+    }
+    wi_o[0] = wi.x; wi_o[1] = wi.y; wi_o[2] = wi.z;
+    return 1;
+}
+
+static void trace_pixel(const pto_scene *s, const pto_params *p, uint32_t x, uint32_t y, float out[4], pto_stats *st)
+{
+    float acc[4] = { 0, 0, 0, 0 };
+    uint32_t pixel = y * p->width + x;
+    for (uint32_t si = 0; si < p->spp; ++si) {
+        uint32_t key = pto_path_key(p->seed, pixel, p->sample_offset + si);
+        float of[3], df[3];
+        pto_camera_ray(&s->cam, x, y, key, of, df);
+        v3 o = ld3(of), d = ld3(df);
+        float T[3] = { 1.0f, 1.0f, 1.0f };
+        uint32_t depth = 0;
+        for (;;) {
+            hit_t h;
+            closest_hit(s, o, d, &h, st);
+            st->rays++;
+            depth++;
+            if (h.id == PTO_MISS) {
+                for (int k = 0; k < 3; ++k) acc[k] = fma_(T[k], s->sky[k], acc[k]);
+                break;
+            }
+            v3 P = madd3(h.t, d, o), ng;
+            uint32_t mat;
+            if (h.is_sphere) {
+                const float *sp = s->spheres + (size_t)h.sph * 4;
+                float ir = 1.0f / sp[3];
+                ng = mk((P.x - sp[0]) * ir, (P.y - sp[1]) * ir, (P.z - sp[2]) * ir);
+                mat = s->sph_mat ? s->sph_mat[h.sph] : 0;
+            } else {
+                ng = norm3(cross3(h.tri.e1, h.tri.e2));
+                mat = h.tri.mat;
+            }
+            int front = dot3(ng, d) < 0.0f;
+            v3 n = front ? ng : mk(-ng.x, -ng.y, -ng.z);
+            const pto_material *m = s->mats + mat;
+            if (m->emission[0] != 0.0f || m->emission[1] != 0.0f || m->emission[2] != 0.0f)
+                for (int k = 0; k < 3; ++k) acc[k] = fma_(T[k], m->emission[k], acc[k]);
+            if (depth >= p->max_depth) break;
+            uint32_t b = depth - 1;
+            float u1 = pto_u01(key, 4 + 4 * b), u2 = pto_u01(key, 5 + 4 * b), u3 = pto_u01(key, 6 + 4 * b);
+            float dv[3] = { d.x, d.y, d.z }, nv[3] = { n.x, n.y, n.z }, wi[3], W[3], side;
+            if (!pto_bsdf_sample(m, dv, nv, front, u1, u2, u3, wi, W, &side)) break;
+            for (int k = 0; k < 3; ++k) T[k] = T[k] * W[k];
+            if (depth >= p->rr_start) {
+                float qrr = min_(max_(T[0], max_(T[1], T[2])), 0.95f);
+                if (!(pto_u01(key, 7 + 4 * b) < qrr)) break;
+                float iq = 1.0f / qrr;
+                for (int k = 0; k < 3; ++k) T[k] = T[k] * iq;
+            }
+            o = madd3(side * p->ray_eps, n, P);
+            d = ld3(wi);
+        }
+        acc[3] += 1.0f;
+        st->paths++;
+    }
+    float is = 1.0f / (float)p->spp;
+    for (int k = 0; k < 4; ++k) out[k] = acc[k] * is;
+}
+
+int pto_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int pto_render(const pto_scene *s, const pto_params *p, int threads, float *rgba, pto_stats *st)
+{
+    if (!s || !p || !rgba || p->spp == 0 || p->width == 0 || p->height == 0) return -1;
+    if (s->n_spheres > 64) return -2;
+    for (uint32_t i = 0; i < s->n_tris; ++i) if (s->tri_mat && s->tri_mat[i] >= s->n_mats) return -3;
+    for (uint32_t i = 0; i < s->n_spheres; ++i) if (s->sph_mat && s->sph_mat[i] >= s->n_mats) return -3;
+    if ((s->n_tris || s->n_spheres) && s->n_mats == 0) return -3;
+    if (s->nodes && s->bvh_width != 2 && s->bvh_width != 4) return -4;
+    pto_stats tot; memset(&tot, 0, sizeof tot);
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+    int H = (int)p->height;
+#pragma omp parallel
+    {
+        pto_stats loc; memset(&loc, 0, sizeof loc);
+#pragma omp for schedule(dynamic, 1)
+        for (int y = 0; y < H; ++y)
+            for (uint32_t x = 0; x < p->width; ++x)
+                trace_pixel(s, p, x, (uint32_t)y, rgba + ((size_t)y * p->width + x) * 4, &loc);
+#pragma omp critical
+        {
+            tot.rays += loc.rays; tot.paths += loc.paths; tot.node_visits += loc.node_visits;
+            tot.tri_tests += loc.tri_tests; tot.sphere_tests += loc.sphere_tests;
+        }
+    }
+    if (st) *st = tot;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ own BVH2 builder (median split) */
+
+typedef struct { float lo[3], hi[3]; } box_t;
+typedef struct {
+    const float *verts; const uint32_t *mats; uint32_t *idx; float *cent; /* 3 per tri */
+    slot_t *nodes; uint32_t n_nodes, cap_nodes; tri48_t *tris; uint32_t n_out;
+} bld_t;
+
+static int g_axis; static const float *g_cent;
+static int cmp_cent(const void *a, const void *b)
+{
+    float ca = g_cent[(size_t)(*(const uint32_t *)a) * 3 + g_axis], cb = g_cent[(size_t)(*(const uint32_t *)b) * 3 + g_axis];
+    if (ca < cb) return -1;
+    if (ca > cb) return 1;
+    uint32_t ia = *(const uint32_t *)a, ib = *(const uint32_t *)b;
+    return ia < ib ? -1 : (ia > ib);
+}
+static inline float pad_of(float c) { return 1e-6f * max_(1.0f, fabsf(c)); }
+static box_t tri_box_padded(const float *p)
+{
+    box_t b;
+    for (int k = 0; k < 3; ++k) {
+        float lo = min_(p[k], min_(p[3 + k], p[6 + k])), hi = max_(p[k], max_(p[3 + k], p[6 + k]));
+        b.lo[k] = lo - pad_of(lo); b.hi[k] = hi + pad_of(hi);
+    }
+    return b;
+}
+static void box_merge(box_t *a, const box_t *b)
+{
+    for (int k = 0; k < 3; ++k) { a->lo[k] = min_(a->lo[k], b->lo[k]); a->hi[k] = max_(a->hi[k], b->hi[k]); }
+}
+/* builds subtree over idx[begin,end); returns ref and its box */
+static int32_t build_rec(bld_t *B, uint32_t begin, uint32_t end, box_t *out)
+{
+    uint32_t n = end - begin;
+    if (n <= 4) {
+        uint32_t first = B->n_out;
+        box_t bb = { { INFINITY, INFINITY, INFINITY }, { -INFINITY, -INFINITY, -INFINITY } };
+        for (uint32_t i = begin; i < end; ++i) {
+            uint32_t id = B->idx[i];
+            const float *p = B->verts + (size_t)id * 9;
+            tri48_t *t = B->tris + B->n_out++;
+            memset(t, 0, sizeof *t);
+            for (int k = 0; k < 3; ++k) { t->v0[k] = p[k]; t->e1[k] = p[3 + k] - p[k]; t->e2[k] = p[6 + k] - p[k]; }
+            t->id = id; t->mat = B->mats ? B->mats[id] : 0;
+            box_t tb = tri_box_padded(p); box_merge(&bb, &tb);
+        }
+        *out = bb;
+        return (int32_t)~((first << 3) | (n - 1));
+    }
+    float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (uint32_t i = begin; i < end; ++i)
+        for (int k = 0; k < 3; ++k) {
+            float c = B->cent[(size_t)B->idx[i] * 3 + k];
+            clo[k] = min_(clo[k], c); chi[k] = max_(chi[k], c);
+        }
+    int ax = 0;
+    if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+    if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+    g_axis = ax; g_cent = B->cent;
+    qsort(B->idx + begin, n, sizeof(uint32_t), cmp_cent);
+    uint32_t mid = begin + n / 2;
+    uint32_t me = B->n_nodes++;
+    box_t b0, b1;
+    int32_t r0 = build_rec(B, begin, mid, &b0);
+    int32_t r1 = build_rec(B, mid, end, &b1);
+    slot_t *nd = B->nodes + (size_t)me * 2;
+    memset(nd, 0, 2 * sizeof(slot_t));
+    for (int k = 0; k < 3; ++k) { nd[0].lo[k] = b0.lo[k]; nd[0].hi[k] = b0.hi[k]; nd[1].lo[k] = b1.lo[k]; nd[1].hi[k] = b1.hi[k]; }
+    nd[0].ref = r0; nd[1].ref = r1;
+    *out = b0; box_merge(out, &b1);
+    return (int32_t)me;
+}
+
+int pto_bvh_build(uint32_t n_tris, const float *tri_verts, const uint32_t *tri_mat,
+                  uint32_t *n_nodes, void **nodes, void **tris48)
+{
+    if (!n_tris || !tri_verts || !n_nodes || !nodes || !tris48) return -1;
+    bld_t B; memset(&B, 0, sizeof B);
+    B.verts = tri_verts; B.mats = tri_mat;
+    B.idx = (uint32_t *)malloc(sizeof(uint32_t) * n_tris);
+    B.cent = (float *)malloc(sizeof(float) * 3 * n_tris);
+    B.cap_nodes = n_tris + 1;
+    B.nodes = (slot_t *)calloc((size_t)B.cap_nodes * 2, sizeof(slot_t));
+    B.tris = (tri48_t *)calloc(n_tris, sizeof(tri48_t));
+    if (!B.idx || !B.cent || !B.nodes || !B.tris) return -2;
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        B.idx[i] = i;
+        const float *p = tri_verts + (size_t)i * 9;
+        for (int k = 0; k < 3; ++k) B.cent[(size_t)i * 3 + k] = (p[k] + p[3 + k] + p[6 + k]) * (1.0f / 3.0f);
+    }
+    box_t rb;
+    if (n_tris <= 4) { /* root must be an inner node: one leaf child + one empty slot */
+        B.n_nodes = 1;
+        int32_t r = build_rec(&B, 0, n_tris, &rb);
+        for (int k = 0; k < 3; ++k) { B.nodes[0].lo[k] = rb.lo[k]; B.nodes[0].hi[k] = rb.hi[k]; B.nodes[1].lo[k] = INFINITY; B.nodes[1].hi[k] = -INFINITY; }
+        B.nodes[0].ref = r; B.nodes[1].ref = PTO_BVH_EMPTY;
+    } else {
+        build_rec(&B, 0, n_tris, &rb);
+    }
+    free(B.idx); free(B.cent);
+    *n_nodes = B.n_nodes; *nodes = B.nodes; *tris48 = B.tris;
+    return 0;
+}
+void pto_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------ blob validation */
+
+int pto_bvh_validate(uint32_t width, uint32_t n_nodes, const void *nodes_v, const void *tris_v,
+                     uint32_t n_tris, const float *tri_verts, const uint32_t *tri_mat, uint32_t *max_depth_out)
+{
+    if (width != 2 && width != 4) return -1;
+    if (n_tris == 0) return n_nodes == 0 ? 0 : -2;
+    if (n_nodes == 0 || !nodes_v || !tris_v) return -2;
+    const slot_t *nodes = (const slot_t *)nodes_v;
+    const tri48_t *tris = (const tri48_t *)tris_v;
+    uint8_t *seen = (uint8_t *)calloc(n_tris, 1), *nseen = (uint8_t *)calloc(n_nodes, 1);
+    typedef struct { int32_t ref; box_t box; uint32_t depth; } ent;
+    ent *stk = (ent *)malloc(sizeof(ent) * (size_t)(n_nodes * (width - 1) + 8));
+    int rc = 0; uint32_t sp = 0, maxd = 0;
+    ent root; root.ref = 0; root.depth = 1;
+    for (int k = 0; k < 3; ++k) { root.box.lo[k] = -INFINITY; root.box.hi[k] = INFINITY; }
+    stk[sp++] = root;
+    while (sp && !rc) {
+        ent e = stk[--sp];
+        if (e.depth > maxd) maxd = e.depth;
+        if (e.depth > 64) { rc = -3; break; }
+        if (e.ref >= 0) {
+            if ((uint32_t)e.ref >= n_nodes) { rc = -4; break; }
+            if (nseen[e.ref]++) { rc = -5; break; } /* node reachable twice */
+            const slot_t *nd = nodes + (size_t)e.ref * width;
+            int any = 0;
+            for (uint32_t c = 0; c < width; ++c) {
+                if (nd[c].ref == PTO_BVH_EMPTY) continue;
+                any = 1;
+                ent ch; ch.ref = nd[c].ref; ch.depth = e.depth + 1;
+                for (int k = 0; k < 3; ++k) {
+                    ch.box.lo[k] = nd[c].lo[k]; ch.box.hi[k] = nd[c].hi[k];
+                    if (!(nd[c].lo[k] >= e.box.lo[k] && nd[c].hi[k] <= e.box.hi[k])) rc = -6; /* child outside parent */
+                }
+                stk[sp++] = ch;
+            }
+            if (!any) rc = -7;
+        } else {
+            uint32_t enc = (uint32_t)~e.ref, first = enc >> 3, cnt = (enc & 7u) + 1u;
+            if ((uint64_t)first + cnt > n_tris) { rc = -8; break; }
+            for (uint32_t j = 0; j < cnt && !rc; ++j) {
+                const tri48_t *t = tris + first + j;
+                if (t->id >= n_tris) { rc = -9; break; }
+                if (seen[t->id]++) { rc = -10; break; }
+                const float *p = tri_verts + (size_t)t->id * 9;
+                for (int k = 0; k < 3; ++k) {
+                    if (t->v0[k] != p[k] || t->e1[k] != p[3 + k] - p[k] || t->e2[k] != p[6 + k] - p[k]) rc = -11;
+                    float lo = min_(p[k], min_(p[3 + k], p[6 + k])), hi = max_(p[k], max_(p[3 + k], p[6 + k]));
+                    /* triangle must sit inside its leaf box with the SPEC §4.1 outward padding */
+                    if (!(e.box.lo[k] <= lo - pad_of(lo) && e.box.hi[k] >= hi + pad_of(hi))) rc = -12;
+                }
+                if (t->mat != (tri_mat ? tri_mat[t->id] : 0)) rc = -14;
+            }
+        }
+    }
+    if (!rc) for (uint32_t i = 0; i < n_tris; ++i) if (seen[i] != 1) { rc = -15; break; }
+    free(seen); free(nseen); free(stk);
+    if (max_depth_out) *max_depth_out = maxd;
+    return rc;
+}
