@@ -1,0 +1,177 @@
+/*
+ * ptrt.h — C ABI of libptrt.so, the MI355X (gfx950) wavefront path tracer that stands where the
+ * reference's Vulkan compute path stands.
+ *
+ * The reference (chairclr/PathTracing) has no plugin/FFI interface; its de-facto seam is the private trio
+ *   Renderer.CreateResources      RayTracing/Graphics/Renderer.cs:105-196   (W x H RGBA image)
+ *   Renderer.CreateComputePipeline RayTracing/Graphics/Renderer.cs:293-403  (load Test.spirv, bind image)
+ *   Renderer.ComputeFrame(delta)  RayTracing/Graphics/Renderer.cs:1006-1040 (CmdDispatch + QueueSubmit)
+ * plus the fence wait in Renderer.Render (Renderer.cs:970-972). Contract of the seam: "after ComputeFrame
+ * and the fence wait, a W x H RGBA image owned by the renderer holds the frame". Each entry point below
+ * names the reference code it replaces. The P/Invoke stub a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions (mirroring the reference's behaviour):
+ *  - every call returns pt_status (0 = ok); nothing throws or aborts across the ABI. The C#/C++/Python host
+ *    wrappers turn non-zero into an exception, as every Vulkan failure does in the reference
+ *    (e.g. Renderer.cs:1022-1025, 1036-1039).
+ *  - a pt_context is single-caller; pt_render is synchronous (returns after the stream is idle), like the
+ *    host-side fence wait at Renderer.cs:972.
+ *  - host arrays passed in are borrowed for the call only; output buffers are caller-allocated.
+ *  - all structs are plain little-endian f32/u32, blittable.
+ *  - there is NO CPU backend: without a gfx950 device pt_context_create fails with PT_ERR_NO_DEVICE.
+ */
+#ifndef PTRT_H
+#define PTRT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTRT_ABI_VERSION 1
+
+typedef int32_t pt_status;
+enum {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARGUMENT = 1,
+    PT_ERR_NO_DEVICE = 2,      /* no HIP device / not gfx950 */
+    PT_ERR_HIP = 3,            /* a HIP runtime call failed; text in pt_last_error */
+    PT_ERR_OUT_OF_MEMORY = 4,
+    PT_ERR_NOT_COMMITTED = 5,  /* scene used before pt_scene_commit */
+    PT_ERR_UNSUPPORTED = 6,
+    PT_ERR_INTERNAL = 7
+};
+
+typedef struct pt_context pt_context; /* opaque; owns the device, stream, path-state queues, framebuffer */
+typedef struct pt_scene pt_scene;     /* opaque; owns host copies, the BVH and the device scene */
+
+/* modes of pt_render */
+enum {
+    PT_REFERENCE_SPHERE = 0, /* exact Test.hlsl:1-40 semantics (docs/SPEC.md §1) */
+    PT_PATH_TRACE = 1        /* wavefront path tracer (docs/SPEC.md §2-§6) */
+};
+/* material kinds */
+enum { PT_LAMBERT = 0, PT_METAL = 1, PT_DIELECTRIC = 2 };
+/* pt_render_params.flags */
+enum {
+    PT_FLAG_PROFILE_KERNELS = 1u, /* bracket every kernel with HIP events on the context's stream; fills pt_stats.*_ms */
+    PT_FLAG_COUNT_VISITS = 2u     /* count BVH node visits / triangle / sphere tests on the device (slower build of extend) */
+};
+/* pt_scene_commit options */
+enum { PT_BVH_WIDTH_DEFAULT = 0, PT_BVH_WIDTH_2 = 2, PT_BVH_WIDTH_4 = 4 };
+
+typedef struct {
+    int32_t device_ordinal; /* hipSetDevice argument; the reference picks its device in GraphicsDevice.cs:38-43 */
+    void *stream;           /* an existing hipStream_t to run on, or NULL to create one */
+    uint32_t flags;         /* reserved, 0 */
+    uint32_t reserved;
+} pt_device_desc;
+
+typedef struct { uint32_t kind; float albedo[3]; float emission[3]; float roughness; float ior; uint32_t pad[3]; } pt_material; /* 48 B */
+
+/* pinhole camera, docs/SPEC.md §3. The reference's literal camera (Test.hlsl:6-10) is
+ * origin (0,0,1), forward (0,0,-1), right (1,0,0), up (0,1,0), scale 2/1080, cx = cy = 1, jitter 0
+ * up to the +0.5 pixel centre that Test.hlsl omits. */
+typedef struct { float origin[3], forward[3], right[3], up[3]; float scale, cx, cy; uint32_t jitter; } pt_camera; /* 64 B */
+
+typedef struct {
+    uint32_t width, height;  /* frame size; the reference hard-codes 1920x1080 (App.cs:27, Renderer.cs:1020) */
+    uint32_t spp;            /* samples per pixel (reference: 1 ray per pixel, Test.hlsl) */
+    uint32_t max_depth;      /* max path segments */
+    uint32_t rr_start;       /* Russian roulette from this depth on */
+    uint32_t seed;
+    uint32_t sample_offset;  /* first sample index (progressive accumulation across calls) */
+    uint32_t mode;           /* PT_REFERENCE_SPHERE | PT_PATH_TRACE */
+    float ray_eps;           /* origin offset along the normal for continuation rays */
+    uint32_t rank, nranks;   /* image-space partition: this process renders tiles t with t % nranks == rank */
+    uint32_t tile_size;      /* 0 = 64 */
+    uint32_t flags;          /* PT_FLAG_* */
+    uint32_t pad[3];
+} pt_render_params; /* 64 B */
+
+typedef struct {
+    uint64_t rays;          /* ray-scene intersection queries = path segments (the benchmark's unit) */
+    uint64_t paths;
+    uint64_t node_visits, tri_tests, sphere_tests; /* only with PT_FLAG_COUNT_VISITS, else 0 */
+    uint32_t iterations;    /* wavefront iterations (extend+shade rounds) */
+    uint32_t extend_launches;
+    double gpu_ms;          /* hipEvent start->stop around all kernels of the frame */
+    double extend_ms;       /* sum of extend-kernel durations (PT_FLAG_PROFILE_KERNELS) */
+    double shade_ms;        /* sum of shade-kernel durations  (PT_FLAG_PROFILE_KERNELS) */
+    double other_ms;        /* generate / resolve kernels */
+    uint64_t reserved[4];
+} pt_stats;
+
+typedef struct {
+    uint32_t width;          /* 2 or 4 */
+    uint32_t n_nodes;
+    uint32_t n_tris;
+    uint32_t max_depth;
+    uint64_t node_bytes;     /* n_nodes * width * 32 */
+    uint64_t tri_bytes;      /* n_tris * 48 */
+    double build_ms;
+    float sah_cost;
+    uint32_t reserved;
+} pt_bvh_info;
+
+/* ---- context: replaces GraphicsDevice.Init (GraphicsDevice.cs:38-43) + Renderer.CreateResources (Renderer.cs:105-196) */
+pt_status pt_context_create(const pt_device_desc *desc, pt_context **out);
+void pt_context_destroy(pt_context *ctx);                 /* Renderer.Dispose, Renderer.cs:1192-1216 */
+const char *pt_last_error(const pt_context *ctx);         /* ctx may be NULL: last error of the calling thread */
+uint32_t pt_abi_version(void);
+
+/* ---- scene: the reference has only shader literals (Test.hlsl:6,8,12,13); this is the API that replaces them */
+pt_status pt_scene_create(pt_context *ctx, pt_scene **out);
+void pt_scene_destroy(pt_scene *scene);
+pt_status pt_scene_set_triangles(pt_scene *s, const float *verts9, const uint32_t *material_ids, uint64_t count);
+pt_status pt_scene_set_spheres(pt_scene *s, const float *cxyzr, const uint32_t *material_ids, uint64_t count);
+pt_status pt_scene_set_materials(pt_scene *s, const pt_material *mats, uint64_t count);
+pt_status pt_scene_set_camera(pt_scene *s, const pt_camera *cam);
+pt_status pt_scene_set_sky(pt_scene *s, const float rgb[3]);
+/* builds the BVH on the host (binned SAH) and uploads everything; replaces CreateComputePipeline's one-time
+ * descriptor/pipeline set-up (Renderer.cs:293-403). bvh_width: PT_BVH_WIDTH_* */
+pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width);
+pt_status pt_scene_bvh_info(const pt_scene *s, pt_bvh_info *out);
+/* copies out the acceleration-structure blob (docs/SPEC.md §4.1) so that a checker can traverse the same bytes */
+pt_status pt_scene_bvh_read(const pt_scene *s, void *nodes, uint64_t node_bytes, void *tris48, uint64_t tri_bytes);
+
+/* ---- frame: replaces Renderer.ComputeFrame (Renderer.cs:1006-1040) + the fence wait (Renderer.cs:970-972) */
+pt_status pt_render(pt_context *ctx, const pt_scene *scene, const pt_render_params *params, pt_stats *stats);
+
+/* ---- results: the reference never reads its image back (it is sampled by the display pass,
+ *      Renderer.cs:1042-1121); these replace that consumer. float4 linear radiance, row-major. */
+pt_status pt_framebuffer_read(pt_context *ctx, float *rgba, uint64_t n_floats);
+pt_status pt_framebuffer_read_rgba8(pt_context *ctx, uint8_t *rgba8, uint64_t n_bytes); /* R8G8B8A8Unorm, Renderer.cs:124 */
+pt_status pt_framebuffer_device_ptr(pt_context *ctx, void **dptr, uint64_t *n_floats);   /* row-major float4 on the device */
+
+/* ---- image-space partition (docs/SPEC.md §6). After pt_render with nranks > 1 the rank's tiles sit
+ * tile-major in a device staging buffer; the host gathers them (RCCL via torch.distributed or
+ * ncclGather) and rank 0 calls pt_assemble_tiles on the gathered buffer. */
+typedef struct {
+    uint32_t tile_size, tiles_x, tiles_y, n_tiles;
+    uint32_t tiles_mine;      /* tiles owned by params.rank */
+    uint32_t tiles_per_rank;  /* max over ranks = stride of one rank's block in the gathered buffer, in tiles */
+    uint64_t floats_per_tile; /* tile_size^2 * 4 */
+} pt_tile_layout;
+pt_status pt_tile_layout_query(const pt_render_params *params, pt_tile_layout *out);
+pt_status pt_tiles_device_ptr(pt_context *ctx, void **dptr, uint64_t *n_floats); /* tiles_per_rank*floats_per_tile floats */
+/* gathered = nranks blocks of tiles_per_rank*floats_per_tile floats (device pointer on ctx's device) */
+pt_status pt_assemble_tiles(pt_context *ctx, const pt_render_params *params, const void *gathered_dptr, uint64_t n_floats);
+
+/* ---- deterministic synthetic scenes (C1..C5); host only, no device needed.
+ * Two-call pattern: pass NULL arrays to get counts, then buffers of those sizes. */
+enum {
+    PT_SCENE_CORNELL = 0,        /* C1/C2: 5 walls (10 tris) + emissive ceiling quad (2 tris) + 4 Lambert spheres */
+    PT_SCENE_CORNELL_GLASS = 1,  /* C4: same box, spheres = dielectric, metal (rough), 2 Lambert */
+    PT_SCENE_TRIANGLE_SOUP = 2,  /* C3: `detail` random triangles in [-1,1]^3, sky emitter */
+    PT_SCENE_CORNELL_TESS = 3    /* C5: Cornell with walls tessellated to ~`detail` triangles */
+};
+typedef struct { uint64_t n_tris, n_spheres, n_mats; } pt_scene_counts;
+pt_status pt_scenegen(uint32_t kind, uint32_t detail, uint32_t seed, uint32_t width, uint32_t height,
+                      pt_scene_counts *counts, float *verts9, uint32_t *tri_mat, float *spheres, uint32_t *sph_mat,
+                      pt_material *mats, pt_camera *cam, float sky[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

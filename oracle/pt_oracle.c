@@ -386,6 +386,7 @@ static void trace_pixel(const pto_scene *s, const pto_params *p, uint32_t x, uin
             float dv[3] = { d.x, d.y, d.z }, nv[3] = { n.x, n.y, n.z }, wi[3], W[3], side;
             if (!pto_bsdf_sample(m, dv, nv, front, u1, u2, u3, wi, W, &side)) break;
             for (int k = 0; k < 3; ++k) T[k] = T[k] * W[k];
+            if (!(max_(T[0], max_(T[1], T[2])) > 0.0f)) break;
             if (depth >= p->rr_start) {
                 float qrr = min_(max_(T[0], max_(T[1], T[2])), 0.95f);
                 if (!(pto_u01(key, 7 + 4 * b) < qrr)) break;
@@ -569,7 +570,7 @@ int pto_bvh_validate(uint32_t width, uint32_t n_nodes, const void *nodes_v, cons
     while (sp && !rc) {
         ent e = stk[--sp];
         if (e.depth > maxd) maxd = e.depth;
-        if (e.depth > 64) { rc = -3; break; }
+        if (e.depth > 96) { rc = -3; break; }
         if (e.ref >= 0) {
             if ((uint32_t)e.ref >= n_nodes) { rc = -4; break; }
             if (nseen[e.ref]++) { rc = -5; break; } /* node reachable twice */

@@ -1,0 +1,106 @@
+"""ctypes binding of libptrt.so (include/ptrt.h). Plumbing only: every symbol the header declares, nothing else.
+
+There is no fallback: if the HIP library is missing this module raises at import, and without a gfx950 device
+`pt_context_create` fails with PT_ERR_NO_DEVICE (the product path never routes through oracle/ or the CPU).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptrt.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C pathtracing_amd/csrc` (hipcc --offload-arch=gfx950) "
+        "or `python -c 'import __graft_entry__ as g; g.build()'`. libptrt has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+# status codes / enums (ptrt.h)
+PT_OK, PT_ERR_INVALID_ARGUMENT, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_OUT_OF_MEMORY, PT_ERR_NOT_COMMITTED, \
+    PT_ERR_UNSUPPORTED, PT_ERR_INTERNAL = range(8)
+PT_REFERENCE_SPHERE, PT_PATH_TRACE = 0, 1
+PT_LAMBERT, PT_METAL, PT_DIELECTRIC = 0, 1, 2
+PT_FLAG_PROFILE_KERNELS, PT_FLAG_COUNT_VISITS = 1, 2
+PT_SCENE_CORNELL, PT_SCENE_CORNELL_GLASS, PT_SCENE_TRIANGLE_SOUP, PT_SCENE_CORNELL_TESS = 0, 1, 2, 3
+
+
+class pt_device_desc(C.Structure):
+    _fields_ = [("device_ordinal", C.c_int32), ("stream", C.c_void_p), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class pt_material(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("albedo", C.c_float * 3), ("emission", C.c_float * 3),
+                ("roughness", C.c_float), ("ior", C.c_float), ("pad", C.c_uint32 * 3)]
+
+
+class pt_camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("forward", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3),
+                ("scale", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("jitter", C.c_uint32)]
+
+
+class pt_render_params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("max_depth", C.c_uint32),
+                ("rr_start", C.c_uint32), ("seed", C.c_uint32), ("sample_offset", C.c_uint32), ("mode", C.c_uint32),
+                ("ray_eps", C.c_float), ("rank", C.c_uint32), ("nranks", C.c_uint32), ("tile_size", C.c_uint32),
+                ("flags", C.c_uint32), ("pad", C.c_uint32 * 3)]
+
+
+class pt_stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("sphere_tests", C.c_uint64), ("iterations", C.c_uint32), ("extend_launches", C.c_uint32),
+                ("gpu_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("other_ms", C.c_double),
+                ("reserved", C.c_uint64 * 4)]
+
+
+class pt_bvh_info(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("n_nodes", C.c_uint32), ("n_tris", C.c_uint32), ("max_depth", C.c_uint32),
+                ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64), ("build_ms", C.c_double),
+                ("sah_cost", C.c_float), ("reserved", C.c_uint32)]
+
+
+class pt_tile_layout(C.Structure):
+    _fields_ = [("tile_size", C.c_uint32), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("n_tiles", C.c_uint32),
+                ("tiles_mine", C.c_uint32), ("tiles_per_rank", C.c_uint32), ("floats_per_tile", C.c_uint64)]
+
+
+class pt_scene_counts(C.Structure):
+    _fields_ = [("n_tris", C.c_uint64), ("n_spheres", C.c_uint64), ("n_mats", C.c_uint64)]
+
+
+assert C.sizeof(pt_material) == 48 and C.sizeof(pt_camera) == 64 and C.sizeof(pt_render_params) == 64
+
+_vp, _u32, _u64, _st = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+_P = C.POINTER
+
+# name -> (restype, argtypes): exactly the entry points of include/ptrt.h
+SYMBOLS = {
+    "pt_abi_version": (_u32, []),
+    "pt_context_create": (_st, [_P(pt_device_desc), _P(_vp)]),
+    "pt_context_destroy": (None, [_vp]),
+    "pt_last_error": (C.c_char_p, [_vp]),
+    "pt_scene_create": (_st, [_vp, _P(_vp)]),
+    "pt_scene_destroy": (None, [_vp]),
+    "pt_scene_set_triangles": (_st, [_vp, _vp, _vp, _u64]),
+    "pt_scene_set_spheres": (_st, [_vp, _vp, _vp, _u64]),
+    "pt_scene_set_materials": (_st, [_vp, _vp, _u64]),
+    "pt_scene_set_camera": (_st, [_vp, _P(pt_camera)]),
+    "pt_scene_set_sky": (_st, [_vp, _P(C.c_float * 3)]),
+    "pt_scene_commit": (_st, [_vp, _u32]),
+    "pt_scene_bvh_info": (_st, [_vp, _P(pt_bvh_info)]),
+    "pt_scene_bvh_read": (_st, [_vp, _vp, _u64, _vp, _u64]),
+    "pt_render": (_st, [_vp, _vp, _P(pt_render_params), _P(pt_stats)]),
+    "pt_framebuffer_read": (_st, [_vp, _vp, _u64]),
+    "pt_framebuffer_read_rgba8": (_st, [_vp, _vp, _u64]),
+    "pt_framebuffer_device_ptr": (_st, [_vp, _P(_vp), _P(_u64)]),
+    "pt_tile_layout_query": (_st, [_P(pt_render_params), _P(pt_tile_layout)]),
+    "pt_tiles_device_ptr": (_st, [_vp, _P(_vp), _P(_u64)]),
+    "pt_assemble_tiles": (_st, [_vp, _P(pt_render_params), _vp, _u64]),
+    "pt_scenegen": (_st, [_u32, _u32, _u32, _u32, _u32, _P(pt_scene_counts), _vp, _vp, _vp, _vp, _vp, _P(pt_camera), _vp]),
+}
+
+for _name, (_res, _args) in SYMBOLS.items():
+    _f = getattr(lib, _name)  # AttributeError here = the library does not export what the header declares
+    _f.restype = _res
+    _f.argtypes = _args

@@ -1,0 +1,548 @@
+// api.cpp — C ABI of libptrt.so (include/ptrt.h): context, scene, wavefront frame loop.
+// Stands where Renderer.CreateResources / CreateComputePipeline / ComputeFrame + the compute-fence wait stand in
+// the reference (RayTracing/Graphics/Renderer.cs:105-196, 293-403, 1006-1040, 970-972).
+// HIP only: there is no CPU fallback anywhere in this library.
+#include "ptrt_internal.h"
+#include "bvh_build.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ptrt;
+
+namespace {
+
+thread_local std::string g_err;
+
+constexpr uint32_t kLag = 4; // wavefront iterations kept in flight before the host looks at a queue size
+
+uint32_t host_pcg(uint32_t x)
+{
+    uint32_t s = x * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (w >> 22) ^ w;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    hipError_t ensure(size_t count)
+    {
+        if (count <= n && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) n = count ? count : 1;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+} // namespace
+
+struct pt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // path state
+    DevBuf<float4> ray_o, ray_d, thr, acc, fb;
+    DevBuf<float2> hit;
+    DevBuf<uint32_t> sd, q_ext0, q_ext1, q_b[B_COUNT], counters, fb8;
+    DevBuf<int32_t> stack_ovf;
+    uint32_t *h_counts = nullptr; // pinned: kLag queue sizes + C_COUNT counters
+    hipEvent_t ev_lag[kLag] = {};
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    uint32_t fb_w = 0, fb_h = 0;
+    uint32_t n_slots = 0; // slots of the last path-traced frame (acc layout)
+    bool fb_valid = false;
+};
+
+struct pt_scene {
+    pt_context *ctx = nullptr;
+    std::vector<float> verts; std::vector<uint32_t> tri_mat;
+    std::vector<float> spheres; std::vector<uint32_t> sph_mat;
+    std::vector<pt_material> mats;
+    pt_camera cam{};
+    float sky[3] = { 0.f, 0.f, 0.f };
+    bool have_cam = false, committed = false;
+    BvhBlob bvh;
+    DevBuf<float4> d_nodes, d_tris, d_spheres, d_mats;
+    DevBuf<uint32_t> d_sph_mat;
+    DeviceScene ds{};
+};
+
+namespace {
+
+pt_status fail(pt_context *ctx, pt_status code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                          \
+    do { hipError_t _e = (expr);                                                                    \
+         if (_e != hipSuccess)                                                                      \
+             return fail(ctx, _e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP,        \
+                         "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+bool finite3(const float *p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+
+pt_status layout_of(const pt_render_params *p, pt_tile_layout *o)
+{
+    if (!p || !o) return PT_ERR_INVALID_ARGUMENT;
+    if (p->width == 0 || p->height == 0 || p->width > 32768 || p->height > 32768) return PT_ERR_INVALID_ARGUMENT;
+    if (p->tile_size != 0 && p->tile_size != kTile) return PT_ERR_UNSUPPORTED;
+    const uint32_t nr = p->nranks ? p->nranks : 1u;
+    if (p->rank >= nr) return PT_ERR_INVALID_ARGUMENT;
+    o->tile_size = kTile;
+    o->tiles_x = (p->width + kTile - 1) / kTile;
+    o->tiles_y = (p->height + kTile - 1) / kTile;
+    o->n_tiles = o->tiles_x * o->tiles_y;
+    o->tiles_mine = (o->n_tiles > p->rank) ? (o->n_tiles - p->rank + nr - 1) / nr : 0u;
+    o->tiles_per_rank = (o->n_tiles + nr - 1) / nr;
+    o->floats_per_tile = (uint64_t)kTilePixels * 4u;
+    return PT_OK;
+}
+
+hipEvent_t pool_event(pt_context *c, size_t i)
+{
+    while (c->ev_pool.size() <= i) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[i];
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t pt_abi_version(void) { return PTRT_ABI_VERSION; }
+
+const char *pt_last_error(const pt_context *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
+{
+    if (!out) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "pt_context_create: out is NULL");
+    *out = nullptr;
+    const int dev = desc ? desc->device_ordinal : 0;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, PT_ERR_NO_DEVICE, "no HIP device visible (%s); libptrt has no CPU backend",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (dev < 0 || dev >= ndev) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "device ordinal %d out of range [0,%d)", dev, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PT_ERR_NO_DEVICE, "device %d is %s; libptrt ships gfx950 (MI355X) code objects only", dev, prop.gcnArchName);
+    HIP_TRY(nullptr, hipSetDevice(dev));
+    pt_context *c = new (std::nothrow) pt_context();
+    if (!c) return fail(nullptr, PT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    c->device = dev;
+    if (desc && desc->stream) { c->stream = (hipStream_t)desc->stream; c->own_stream = false; }
+    else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(nullptr, PT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * (kLag + C_COUNT), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess;
+    for (uint32_t i = 0; ok && i < kLag; ++i) ok = hipEventCreateWithFlags(&c->ev_lag[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && c->counters.ensure(C_COUNT) == hipSuccess;
+    if (!ok) { pt_context_destroy(c); return fail(nullptr, PT_ERR_HIP, "context resource creation failed"); }
+    *out = c;
+    return PT_OK;
+}
+
+void pt_context_destroy(pt_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->ray_o.release(); c->ray_d.release(); c->thr.release(); c->acc.release(); c->fb.release(); c->hit.release();
+    c->sd.release(); c->q_ext0.release(); c->q_ext1.release(); c->counters.release(); c->fb8.release(); c->stack_ovf.release();
+    for (auto &q : c->q_b) q.release();
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    for (auto &e : c->ev_lag) if (e) (void)hipEventDestroy(e);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------------------------------------ scene
+
+pt_status pt_scene_create(pt_context *ctx, pt_scene **out)
+{
+    // ctx == NULL makes a detached (host-only) scene: commit builds the BVH blob for pt_scene_bvh_read/info,
+    // nothing is uploaded and pt_render rejects it. Used to check the builder where no device exists.
+    if (!out) return fail(ctx, PT_ERR_INVALID_ARGUMENT, "pt_scene_create: NULL argument");
+    pt_scene *s = new (std::nothrow) pt_scene();
+    if (!s) return fail(ctx, PT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->ctx = ctx;
+    *out = s;
+    return PT_OK;
+}
+
+void pt_scene_destroy(pt_scene *s)
+{
+    if (!s) return;
+    if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
+    s->d_nodes.release(); s->d_tris.release(); s->d_spheres.release(); s->d_mats.release(); s->d_sph_mat.release();
+    delete s;
+}
+
+pt_status pt_scene_set_triangles(pt_scene *s, const float *verts9, const uint32_t *material_ids, uint64_t count)
+{
+    if (!s) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (count && !verts9) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "verts9 is NULL");
+    if (count >= (1ull << 28)) return fail(s->ctx, PT_ERR_UNSUPPORTED, "more than 2^28 triangles");
+    for (uint64_t i = 0; i < count * 9; ++i)
+        if (!std::isfinite(verts9[i])) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "non-finite vertex coordinate at float %llu", (unsigned long long)i);
+    s->verts.assign(verts9, verts9 + count * 9);
+    if (material_ids) s->tri_mat.assign(material_ids, material_ids + count); else s->tri_mat.assign(count, 0u);
+    s->committed = false;
+    return PT_OK;
+}
+
+pt_status pt_scene_set_spheres(pt_scene *s, const float *cxyzr, const uint32_t *material_ids, uint64_t count)
+{
+    if (!s) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (count && !cxyzr) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "cxyzr is NULL");
+    if (count > kMaxSpheres) return fail(s->ctx, PT_ERR_UNSUPPORTED, "more than %u spheres (they are a flat list)", kMaxSpheres);
+    for (uint64_t i = 0; i < count; ++i)
+        if (!finite3(cxyzr + i * 4) || !(cxyzr[i * 4 + 3] > 0.f) || !std::isfinite(cxyzr[i * 4 + 3]))
+            return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "sphere %llu: non-finite centre or radius <= 0", (unsigned long long)i);
+    s->spheres.assign(cxyzr, cxyzr + count * 4);
+    if (material_ids) s->sph_mat.assign(material_ids, material_ids + count); else s->sph_mat.assign(count, 0u);
+    s->committed = false;
+    return PT_OK;
+}
+
+pt_status pt_scene_set_materials(pt_scene *s, const pt_material *mats, uint64_t count)
+{
+    if (!s) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (count && !mats) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "mats is NULL");
+    for (uint64_t i = 0; i < count; ++i) {
+        if (mats[i].kind > PT_DIELECTRIC) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "material %llu: unknown kind %u", (unsigned long long)i, mats[i].kind);
+        if (!finite3(mats[i].albedo) || !finite3(mats[i].emission) || !std::isfinite(mats[i].roughness) || !std::isfinite(mats[i].ior))
+            return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "material %llu: non-finite field", (unsigned long long)i);
+        if (mats[i].roughness < 0.f || mats[i].roughness > 1.f) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "material %llu: roughness outside [0,1]", (unsigned long long)i);
+        if (mats[i].kind == PT_DIELECTRIC && !(mats[i].ior > 0.f)) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "material %llu: ior <= 0", (unsigned long long)i);
+    }
+    s->mats.assign(mats, mats + count);
+    s->committed = false;
+    return PT_OK;
+}
+
+pt_status pt_scene_set_camera(pt_scene *s, const pt_camera *cam)
+{
+    if (!s || !cam) return fail(s ? s->ctx : nullptr, PT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!finite3(cam->origin) || !finite3(cam->forward) || !finite3(cam->right) || !finite3(cam->up) ||
+        !std::isfinite(cam->scale) || !std::isfinite(cam->cx) || !std::isfinite(cam->cy))
+        return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "camera has a non-finite field");
+    s->cam = *cam; s->have_cam = true;
+    if (s->committed) s->ds.cam = *cam; // camera changes do not need a re-commit
+    return PT_OK;
+}
+
+pt_status pt_scene_set_sky(pt_scene *s, const float rgb[3])
+{
+    if (!s || !rgb) return fail(s ? s->ctx : nullptr, PT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!finite3(rgb)) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "sky is not finite");
+    for (int k = 0; k < 3; ++k) { s->sky[k] = rgb[k]; s->ds.sky[k] = rgb[k]; }
+    return PT_OK;
+}
+
+pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
+{
+    if (!s) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    pt_context *c = s->ctx;
+    if (bvh_width == PT_BVH_WIDTH_DEFAULT) bvh_width = PT_BVH_WIDTH_4;
+    if (bvh_width != 2 && bvh_width != 4) return fail(c, PT_ERR_INVALID_ARGUMENT, "bvh_width must be 0, 2 or 4");
+    if (!s->have_cam) return fail(c, PT_ERR_INVALID_ARGUMENT, "no camera set");
+    const uint32_t nt = (uint32_t)s->tri_mat.size(), ns = (uint32_t)s->sph_mat.size(), nm = (uint32_t)s->mats.size();
+    if ((nt || ns) && nm == 0) return fail(c, PT_ERR_INVALID_ARGUMENT, "primitives but no materials");
+    for (uint32_t i = 0; i < nt; ++i) if (s->tri_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "triangle %u: material id %u >= %u", i, s->tri_mat[i], nm);
+    for (uint32_t i = 0; i < ns; ++i) if (s->sph_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "sphere %u: material id %u >= %u", i, s->sph_mat[i], nm);
+
+    build_bvh(s->verts.data(), s->tri_mat.data(), nt, bvh_width, s->bvh);
+    if (s->bvh.max_depth > 90) return fail(c, PT_ERR_INTERNAL, "BVH depth %u exceeds the supported 90", s->bvh.max_depth);
+    if (!c) { s->committed = true; return PT_OK; } // detached scene: host-side blob only
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    static_assert(sizeof(BvhSlot) == 32 && sizeof(BvhTri) == 48 && sizeof(pt_material) == 48, "blob layout");
+    HIP_TRY(c, s->d_nodes.ensure(s->bvh.slots.size() * 2));
+    HIP_TRY(c, s->d_tris.ensure(s->bvh.tris.size() * 3));
+    HIP_TRY(c, s->d_spheres.ensure(ns));
+    HIP_TRY(c, s->d_sph_mat.ensure(ns));
+    HIP_TRY(c, s->d_mats.ensure((size_t)nm * 3));
+    if (!s->bvh.slots.empty()) HIP_TRY(c, hipMemcpy(s->d_nodes.p, s->bvh.slots.data(), s->bvh.slots.size() * sizeof(BvhSlot), hipMemcpyHostToDevice));
+    if (!s->bvh.tris.empty()) HIP_TRY(c, hipMemcpy(s->d_tris.p, s->bvh.tris.data(), s->bvh.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
+    if (ns) {
+        HIP_TRY(c, hipMemcpy(s->d_spheres.p, s->spheres.data(), (size_t)ns * 16, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(s->d_sph_mat.p, s->sph_mat.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
+    }
+    if (nm) HIP_TRY(c, hipMemcpy(s->d_mats.p, s->mats.data(), (size_t)nm * sizeof(pt_material), hipMemcpyHostToDevice));
+
+    DeviceScene &d = s->ds;
+    d.nodes = s->d_nodes.p; d.tris = s->d_tris.p; d.spheres = s->d_spheres.p; d.sph_mat = s->d_sph_mat.p; d.mats = s->d_mats.p;
+    d.n_nodes = s->bvh.n_nodes; d.n_tris = nt; d.n_spheres = ns; d.n_mats = nm;
+    for (int k = 0; k < 3; ++k) d.sky[k] = s->sky[k];
+    d.bvh_width = bvh_width;
+    d.cam = s->cam;
+    s->committed = true;
+    return PT_OK;
+}
+
+pt_status pt_scene_bvh_info(const pt_scene *s, pt_bvh_info *o)
+{
+    if (!s || !o) return fail(s ? s->ctx : nullptr, PT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!s->committed) return fail(s->ctx, PT_ERR_NOT_COMMITTED, "scene not committed");
+    std::memset(o, 0, sizeof *o);
+    o->width = s->bvh.width; o->n_nodes = s->bvh.n_nodes; o->n_tris = (uint32_t)s->bvh.tris.size();
+    o->max_depth = s->bvh.max_depth;
+    o->node_bytes = (uint64_t)s->bvh.slots.size() * sizeof(BvhSlot);
+    o->tri_bytes = (uint64_t)s->bvh.tris.size() * sizeof(BvhTri);
+    o->build_ms = s->bvh.build_ms; o->sah_cost = s->bvh.sah_cost;
+    o->reserved = s->bvh.stack_need;
+    return PT_OK;
+}
+
+pt_status pt_scene_bvh_read(const pt_scene *s, void *nodes, uint64_t node_bytes, void *tris48, uint64_t tri_bytes)
+{
+    if (!s) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (!s->committed) return fail(s->ctx, PT_ERR_NOT_COMMITTED, "scene not committed");
+    const uint64_t nb = (uint64_t)s->bvh.slots.size() * sizeof(BvhSlot), tb = (uint64_t)s->bvh.tris.size() * sizeof(BvhTri);
+    if (node_bytes < nb || tri_bytes < tb || (nb && !nodes) || (tb && !tris48)) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "buffers too small: need %llu + %llu bytes", (unsigned long long)nb, (unsigned long long)tb);
+    if (nb) std::memcpy(nodes, s->bvh.slots.data(), nb);
+    if (tb) std::memcpy(tris48, s->bvh.tris.data(), tb);
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ frame
+
+pt_status pt_tile_layout_query(const pt_render_params *p, pt_tile_layout *o)
+{
+    pt_status st = layout_of(p, o);
+    if (st != PT_OK) return fail(nullptr, st, "invalid render params for tile layout");
+    return PT_OK;
+}
+
+static pt_status ensure_frame(pt_context *c, uint32_t w, uint32_t h)
+{
+    const size_t n = (size_t)w * h;
+    HIP_TRY(c, c->fb.ensure(n));
+    HIP_TRY(c, c->fb8.ensure(n));
+    c->fb_w = w; c->fb_h = h;
+    return PT_OK;
+}
+
+pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p, pt_stats *stats)
+{
+    if (!c || !p) return fail(c, PT_ERR_INVALID_ARGUMENT, "pt_render: NULL argument");
+    pt_tile_layout lay;
+    pt_status st = layout_of(p, &lay);
+    if (st != PT_OK) return fail(c, st, "pt_render: bad width/height/rank/nranks/tile_size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    pt_stats out; std::memset(&out, 0, sizeof out);
+    c->fb_valid = false;
+    const bool profile = (p->flags & PT_FLAG_PROFILE_KERNELS) != 0, count = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
+
+    if (p->mode == PT_REFERENCE_SPHERE) {
+        // Renderer.ComputeFrame: one dispatch, then the host blocks on the fence (Renderer.cs:1020,1036,972)
+        if ((st = ensure_frame(c, p->width, p->height)) != PT_OK) return st;
+        HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+        HIP_TRY(c, launch_reference_sphere(c->stream, p->width, p->height, c->fb.p, c->fb8.p));
+        HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+        out.gpu_ms = ms; out.other_ms = ms;
+        out.rays = out.paths = (uint64_t)p->width * p->height;
+        out.iterations = 1;
+        c->fb_valid = true;
+        if (stats) *stats = out;
+        return PT_OK;
+    }
+    if (p->mode != PT_PATH_TRACE) return fail(c, PT_ERR_INVALID_ARGUMENT, "unknown mode %u", p->mode);
+    if (!s) return fail(c, PT_ERR_INVALID_ARGUMENT, "pt_render: scene is NULL");
+    if (s->ctx != c) return fail(c, PT_ERR_INVALID_ARGUMENT, "scene belongs to another context");
+    if (!s->committed) return fail(c, PT_ERR_NOT_COMMITTED, "scene not committed");
+    if (p->spp == 0 || p->spp >= (1u << 24)) return fail(c, PT_ERR_INVALID_ARGUMENT, "spp must be in [1, 2^24)");
+    if (p->max_depth == 0 || p->max_depth > 255) return fail(c, PT_ERR_INVALID_ARGUMENT, "max_depth must be in [1,255]");
+    if (!std::isfinite(p->ray_eps) || p->ray_eps < 0.f) return fail(c, PT_ERR_INVALID_ARGUMENT, "ray_eps must be finite and >= 0");
+
+    const uint32_t nranks = p->nranks ? p->nranks : 1u;
+    const uint64_t slots64 = (uint64_t)lay.tiles_per_rank * kTilePixels;
+    if (slots64 >= (1ull << 31)) return fail(c, PT_ERR_UNSUPPORTED, "frame too large");
+    const uint32_t n_slots = (uint32_t)slots64;
+
+    HIP_TRY(c, c->ray_o.ensure(n_slots)); HIP_TRY(c, c->ray_d.ensure(n_slots)); HIP_TRY(c, c->thr.ensure(n_slots));
+    HIP_TRY(c, c->acc.ensure(n_slots)); HIP_TRY(c, c->hit.ensure(n_slots)); HIP_TRY(c, c->sd.ensure(n_slots));
+    HIP_TRY(c, c->q_ext0.ensure(n_slots)); HIP_TRY(c, c->q_ext1.ensure(n_slots));
+    for (auto &q : c->q_b) HIP_TRY(c, q.ensure(n_slots));
+    const uint32_t ovf = s->bvh.stack_need > kStackLds ? s->bvh.stack_need - kStackLds : 0u;
+    if (ovf) HIP_TRY(c, c->stack_ovf.ensure((size_t)ovf * n_slots));
+    if (nranks == 1) { if ((st = ensure_frame(c, p->width, p->height)) != PT_OK) return st; }
+
+    PathState ps{};
+    ps.ray_o = c->ray_o.p; ps.ray_d = c->ray_d.p; ps.hit = c->hit.p; ps.thr = c->thr.p; ps.sd = c->sd.p; ps.acc = c->acc.p;
+    ps.q_ext[0] = c->q_ext0.p; ps.q_ext[1] = c->q_ext1.p;
+    for (uint32_t b = 0; b < B_COUNT; ++b) ps.q_bucket[b] = c->q_b[b].p;
+    ps.counters = c->counters.p; ps.stack_ovf = c->stack_ovf.p; ps.stack_ovf_entries = ovf; ps.n_slots = n_slots;
+
+    FrameParams fp{};
+    fp.width = p->width; fp.height = p->height; fp.spp = p->spp; fp.max_depth = p->max_depth; fp.rr_start = p->rr_start;
+    fp.seed_hashed = host_pcg(p->seed); fp.sample_offset = p->sample_offset; fp.ray_eps = p->ray_eps;
+    fp.rank = p->rank; fp.nranks = nranks; fp.tiles_x = lay.tiles_x; fp.n_tiles = lay.n_tiles;
+
+    const DeviceScene &sc = s->ds;
+    hipStream_t q = c->stream;
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * C_COUNT, q));
+    HIP_TRY(c, hipEventRecord(c->ev_start, q));
+    HIP_TRY(c, launch_generate(q, sc, ps, fp));
+
+    // Wavefront loop. The extend queue can only shrink (slots die, none are born), so a queue size read back
+    // kLag iterations ago is a valid launch bound: the host never stalls the GPU to size a grid.
+    uint32_t bound = n_slots, iters = 0;
+    const uint64_t max_iters = (uint64_t)p->spp * p->max_depth + kLag + 2;
+    size_t nev = 0;
+    bool done = false;
+    while (!done) {
+        if (iters >= max_iters) return fail(c, PT_ERR_INTERNAL, "wavefront loop did not drain after %u iterations", iters);
+        const uint32_t parity = iters & 1u;
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        if (profile) {
+            e0 = pool_event(c, nev++); e1 = pool_event(c, nev++); e2 = pool_event(c, nev++);
+            if (!e0 || !e1 || !e2) return fail(c, PT_ERR_HIP, "hipEventCreate failed");
+            HIP_TRY(c, hipEventRecord(e0, q));
+        }
+        HIP_TRY(c, launch_extend(q, sc, ps, parity, bound, count));
+        if (profile) HIP_TRY(c, hipEventRecord(e1, q));
+        HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound));
+        if (profile) HIP_TRY(c, hipEventRecord(e2, q));
+        const uint32_t ring = iters % kLag;
+        HIP_TRY(c, hipMemcpyAsync(&c->h_counts[ring], c->counters.p + C_EXT0 + (parity ^ 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, q));
+        HIP_TRY(c, hipEventRecord(c->ev_lag[ring], q));
+        ++iters;
+        if (iters >= kLag) {
+            const uint32_t old = (iters - kLag) % kLag; // iteration iters-kLag: its survivors bound every later queue
+            HIP_TRY(c, hipEventSynchronize(c->ev_lag[old]));
+            bound = c->h_counts[old];
+            if (bound == 0) done = true;
+        }
+    }
+    if (nranks == 1)
+        HIP_TRY(c, launch_assemble(q, c->acc.p, 1, n_slots, p->width, p->height, lay.tiles_x, lay.n_tiles, 1.0f / (float)p->spp, c->fb.p, c->fb8.p));
+    HIP_TRY(c, hipEventRecord(c->ev_stop, q));
+    HIP_TRY(c, hipMemcpyAsync(c->h_counts + kLag, c->counters.p, sizeof(uint32_t) * C_COUNT, hipMemcpyDeviceToHost, q));
+    HIP_TRY(c, hipStreamSynchronize(q));
+
+    const uint32_t *hc = c->h_counts + kLag;
+    if (hc[C_ERROR]) return fail(c, PT_ERR_INTERNAL, "device error flag 0x%x (1 = traversal stack overflow, 2 = step limit)", hc[C_ERROR]);
+    if (hc[C_EXT0] || hc[C_EXT1]) return fail(c, PT_ERR_INTERNAL, "extend queue not empty at frame end");
+    float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+    out.gpu_ms = ms;
+    out.rays = (uint64_t)hc[C_RAYS_LO] | ((uint64_t)hc[C_RAYS_HI] << 32);
+    out.node_visits = (uint64_t)hc[C_NODES_LO] | ((uint64_t)hc[C_NODES_LO + 1] << 32);
+    out.tri_tests = (uint64_t)hc[C_TRIS_LO] | ((uint64_t)hc[C_TRIS_LO + 1] << 32);
+    out.sphere_tests = (uint64_t)hc[C_SPH_LO] | ((uint64_t)hc[C_SPH_LO + 1] << 32);
+    out.iterations = iters; out.extend_launches = iters;
+    {   // paths = owned in-image pixels x spp
+        uint64_t px = 0;
+        for (uint32_t t = p->rank; t < lay.n_tiles; t += nranks) {
+            const uint32_t tx = t % lay.tiles_x, ty = t / lay.tiles_x;
+            const uint32_t w = std::min(kTile, p->width - tx * kTile), h = std::min(kTile, p->height - ty * kTile);
+            px += (uint64_t)w * h;
+        }
+        out.paths = px * p->spp;
+    }
+    if (profile) {
+        for (size_t i = 0; i + 2 < nev + 0 && i < nev; i += 3) {
+            float a = 0.f, b = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&a, c->ev_pool[i], c->ev_pool[i + 1]));
+            HIP_TRY(c, hipEventElapsedTime(&b, c->ev_pool[i + 1], c->ev_pool[i + 2]));
+            out.extend_ms += a; out.shade_ms += b;
+        }
+        out.other_ms = out.gpu_ms - out.extend_ms - out.shade_ms;
+    }
+    c->n_slots = n_slots;
+    c->fb_valid = (nranks == 1);
+    if (stats) *stats = out;
+    return PT_OK;
+}
+
+pt_status pt_framebuffer_read(pt_context *c, float *rgba, uint64_t n_floats)
+{
+    if (!c || !rgba) return fail(c, PT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->fb_valid) return fail(c, PT_ERR_NOT_COMMITTED, "no assembled frame (render with nranks == 1 or call pt_assemble_tiles)");
+    const uint64_t need = (uint64_t)c->fb_w * c->fb_h * 4;
+    if (n_floats < need) return fail(c, PT_ERR_INVALID_ARGUMENT, "buffer too small: need %llu floats", (unsigned long long)need);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(rgba, c->fb.p, need * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+pt_status pt_framebuffer_read_rgba8(pt_context *c, uint8_t *rgba8, uint64_t n_bytes)
+{
+    if (!c || !rgba8) return fail(c, PT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->fb_valid) return fail(c, PT_ERR_NOT_COMMITTED, "no assembled frame");
+    const uint64_t need = (uint64_t)c->fb_w * c->fb_h * 4;
+    if (n_bytes < need) return fail(c, PT_ERR_INVALID_ARGUMENT, "buffer too small: need %llu bytes", (unsigned long long)need);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(rgba8, c->fb8.p, need, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+pt_status pt_framebuffer_device_ptr(pt_context *c, void **dptr, uint64_t *n_floats)
+{
+    if (!c || !dptr) return fail(c, PT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->fb_valid) return fail(c, PT_ERR_NOT_COMMITTED, "no assembled frame");
+    *dptr = c->fb.p;
+    if (n_floats) *n_floats = (uint64_t)c->fb_w * c->fb_h * 4;
+    return PT_OK;
+}
+
+pt_status pt_tiles_device_ptr(pt_context *c, void **dptr, uint64_t *n_floats)
+{
+    if (!c || !dptr) return fail(c, PT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->n_slots) return fail(c, PT_ERR_NOT_COMMITTED, "no path-traced frame yet");
+    *dptr = c->acc.p;
+    if (n_floats) *n_floats = (uint64_t)c->n_slots * 4;
+    return PT_OK;
+}
+
+pt_status pt_assemble_tiles(pt_context *c, const pt_render_params *p, const void *gathered, uint64_t n_floats)
+{
+    if (!c || !p || !gathered) return fail(c, PT_ERR_INVALID_ARGUMENT, "NULL argument");
+    pt_tile_layout lay;
+    pt_status st = layout_of(p, &lay);
+    if (st != PT_OK) return fail(c, st, "pt_assemble_tiles: bad params");
+    if (p->spp == 0) return fail(c, PT_ERR_INVALID_ARGUMENT, "spp == 0");
+    const uint32_t nranks = p->nranks ? p->nranks : 1u;
+    const uint64_t per_rank = (uint64_t)lay.tiles_per_rank * kTilePixels;
+    if (n_floats < per_rank * nranks * 4) return fail(c, PT_ERR_INVALID_ARGUMENT, "gathered buffer too small: need %llu floats", (unsigned long long)(per_rank * nranks * 4));
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((st = ensure_frame(c, p->width, p->height)) != PT_OK) return st;
+    HIP_TRY(c, launch_assemble(c->stream, (const float4 *)gathered, nranks, (uint32_t)per_rank, p->width, p->height, lay.tiles_x, lay.n_tiles,
+                               1.0f / (float)p->spp, c->fb.p, c->fb8.p));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->fb_valid = true;
+    return PT_OK;
+}
+
+} // extern "C"

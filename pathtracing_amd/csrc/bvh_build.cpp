@@ -1,0 +1,213 @@
+// bvh_build.cpp — binned-SAH BVH2 build (16 bins/axis), optional SAH-area collapse to BVH4, breadth-first
+// node layout (top levels contiguous => stageable in LDS, one 128-B line per BVH4 node). docs/SPEC.md §4.1.
+#include "bvh_build.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace ptrt {
+namespace {
+
+constexpr int kBins = 16;
+constexpr uint32_t kMaxLeaf = 4;
+constexpr int32_t kEmpty = 0x7fffffff;
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; ++k) { lo[k] = kInf; hi[k] = -kInf; } }
+    void grow(const Box &b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    void grow(const float p[3]) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    float area() const
+    {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return (dx < 0.f) ? 0.f : 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+struct Prim { Box box; float c[3]; };
+struct Tmp { Box box; int32_t left, right; uint32_t first, count; }; // count > 0: leaf over idx[first, first+count)
+
+inline float pad_of(float c) { return 1e-6f * std::max(1.0f, std::fabs(c)); }
+
+struct Builder {
+    const std::vector<Prim> &prims;
+    std::vector<uint32_t> &idx;
+    std::vector<Tmp> nodes;
+    Builder(const std::vector<Prim> &p, std::vector<uint32_t> &i) : prims(p), idx(i) { nodes.reserve(p.size()); }
+
+    int32_t make_leaf(uint32_t b, uint32_t e, const Box &box)
+    {
+        Tmp t; t.box = box; t.left = t.right = -1; t.first = b; t.count = e - b;
+        nodes.push_back(t);
+        return (int32_t)nodes.size() - 1;
+    }
+
+    int32_t build(uint32_t b, uint32_t e, int depth)
+    {
+        const uint32_t n = e - b;
+        Box box, cb;
+        box.reset(); cb.reset();
+        for (uint32_t i = b; i < e; ++i) { box.grow(prims[idx[i]].box); cb.grow(prims[idx[i]].c); }
+        if (n == 1) return make_leaf(b, e, box);
+
+        uint32_t mid = 0;
+        bool have_split = false;
+        if (depth < 40) {
+            float best = kInf; int best_axis = -1, best_bin = -1;
+            for (int ax = 0; ax < 3; ++ax) {
+                const float ext = cb.hi[ax] - cb.lo[ax];
+                if (!(ext > 0.f)) continue;
+                Box bb[kBins]; uint32_t cnt[kBins];
+                for (int k = 0; k < kBins; ++k) { bb[k].reset(); cnt[k] = 0; }
+                const float sc = (float)kBins / ext;
+                for (uint32_t i = b; i < e; ++i) {
+                    const Prim &p = prims[idx[i]];
+                    int k = (int)((p.c[ax] - cb.lo[ax]) * sc);
+                    k = std::min(std::max(k, 0), kBins - 1);
+                    bb[k].grow(p.box); cnt[k]++;
+                }
+                float ra[kBins]; uint32_t rc[kBins];
+                Box acc; acc.reset(); uint32_t c = 0;
+                for (int k = kBins - 1; k >= 1; --k) { acc.grow(bb[k]); c += cnt[k]; ra[k] = acc.area(); rc[k] = c; }
+                acc.reset(); c = 0;
+                for (int k = 0; k < kBins - 1; ++k) {
+                    acc.grow(bb[k]); c += cnt[k];
+                    if (c == 0 || rc[k + 1] == 0) continue;
+                    const float cost = acc.area() * (float)c + ra[k + 1] * (float)rc[k + 1];
+                    if (cost < best) { best = cost; best_axis = ax; best_bin = k; }
+                }
+            }
+            const float leaf_cost = box.area() * (float)n;
+            if (best_axis >= 0 && !(n <= kMaxLeaf && best >= leaf_cost)) {
+                const float ext = cb.hi[best_axis] - cb.lo[best_axis], sc = (float)kBins / ext, lo = cb.lo[best_axis];
+                const int ax = best_axis, bin = best_bin;
+                auto it = std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t id) {
+                    int k = (int)((prims[id].c[ax] - lo) * sc);
+                    k = std::min(std::max(k, 0), kBins - 1);
+                    return k <= bin;
+                });
+                mid = (uint32_t)(it - idx.begin());
+                have_split = mid > b && mid < e;
+            } else if (n <= kMaxLeaf) return make_leaf(b, e, box);
+        }
+        if (!have_split) {
+            if (n <= kMaxLeaf) return make_leaf(b, e, box);
+            int ax = 0; // median split along the widest centroid axis (ties: index order)
+            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;
+            mid = b + n / 2;
+            std::nth_element(idx.begin() + b, idx.begin() + mid, idx.begin() + e, [&](uint32_t x, uint32_t y) {
+                const float cx = prims[x].c[ax], cy = prims[y].c[ax];
+                return cx < cy || (cx == cy && x < y);
+            });
+        }
+        const int32_t me = (int32_t)nodes.size();
+        nodes.push_back(Tmp{});
+        const int32_t l = build(b, mid, depth + 1);
+        const int32_t r = build(mid, e, depth + 1);
+        Tmp &t = nodes[me];
+        t.box = box; t.left = l; t.right = r; t.first = 0; t.count = 0;
+        return me;
+    }
+};
+
+} // namespace
+
+void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    out = BvhBlob{};
+    out.width = width;
+    if (n_tris == 0) return;
+
+    std::vector<Prim> prims(n_tris);
+    std::vector<uint32_t> idx(n_tris);
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        const float *p = verts9 + (size_t)i * 9;
+        Prim &pr = prims[i];
+        for (int k = 0; k < 3; ++k) {
+            const float lo = std::min(p[k], std::min(p[3 + k], p[6 + k])), hi = std::max(p[k], std::max(p[3 + k], p[6 + k]));
+            pr.box.lo[k] = lo - pad_of(lo);
+            pr.box.hi[k] = hi + pad_of(hi);
+            pr.c[k] = 0.5f * (lo + hi);
+        }
+        idx[i] = i;
+    }
+    Builder B(prims, idx);
+    const int32_t root = B.build(0, n_tris, 0);
+    const std::vector<Tmp> &tn = B.nodes;
+
+    // ---- emit: breadth-first over output nodes
+    struct Pending { int32_t kids[4]; int nk; };
+    std::vector<Pending> pend;
+    pend.reserve(tn.size());
+    auto expand = [&](int32_t t) { // children of the output node made from tmp node t
+        Pending p; p.nk = 0;
+        if (tn[t].count) { p.kids[p.nk++] = t; return p; } // (root is a leaf) single child
+        p.kids[p.nk++] = tn[t].left; p.kids[p.nk++] = tn[t].right;
+        while (p.nk < (int)width) {
+            int best = -1; float ba = -1.f;
+            for (int i = 0; i < p.nk; ++i)
+                if (!tn[p.kids[i]].count) { const float a = tn[p.kids[i]].box.area(); if (a > ba) { ba = a; best = i; } }
+            if (best < 0) break;
+            const int32_t c = p.kids[best];
+            for (int i = p.nk; i > best + 1; --i) p.kids[i] = p.kids[i - 1];
+            p.kids[best] = tn[c].left; p.kids[best + 1] = tn[c].right; p.nk++;
+        }
+        return p;
+    };
+    pend.push_back(expand(root));
+    out.tris.reserve(n_tris);
+    out.slots.reserve(tn.size() * width);
+    const float root_area = std::max(tn[root].box.area(), 1e-30f);
+    double sah = 0.0;
+    for (size_t i = 0; i < pend.size(); ++i) { // pend grows while we iterate: index i = output node i
+        const Pending p = pend[i];
+        BvhSlot s[4];
+        for (uint32_t c = 0; c < width; ++c) { std::memset(&s[c], 0, sizeof(BvhSlot)); s[c].ref = kEmpty; }
+        for (int c = 0; c < p.nk; ++c) {
+            const Tmp &k = tn[p.kids[c]];
+            for (int a = 0; a < 3; ++a) { s[c].lo[a] = k.box.lo[a]; s[c].hi[a] = k.box.hi[a]; }
+            if (k.count) {
+                const uint32_t first = (uint32_t)out.tris.size();
+                for (uint32_t j = 0; j < k.count; ++j) {
+                    const uint32_t id = idx[k.first + j];
+                    const float *v = verts9 + (size_t)id * 9;
+                    BvhTri t; std::memset(&t, 0, sizeof t);
+                    for (int a = 0; a < 3; ++a) { t.v0[a] = v[a]; t.e1[a] = v[3 + a] - v[a]; t.e2[a] = v[6 + a] - v[a]; }
+                    t.id = id; t.mat = mats ? mats[id] : 0u;
+                    out.tris.push_back(t);
+                }
+                s[c].ref = (int32_t)~((first << 3) | (k.count - 1u));
+                sah += (double)(k.box.area() / root_area) * k.count;
+            } else {
+                s[c].ref = (int32_t)pend.size();
+                pend.push_back(expand(p.kids[c]));
+                sah += (double)(k.box.area() / root_area);
+            }
+        }
+        for (uint32_t c = 0; c < width; ++c) out.slots.push_back(s[c]);
+    }
+    out.n_nodes = (uint32_t)pend.size();
+    out.sah_cost = (float)sah;
+
+    // ---- depth and worst-case traversal-stack need (children have larger indices than parents)
+    std::vector<uint32_t> depth(out.n_nodes, 1), need(out.n_nodes, 0);
+    for (int64_t i = (int64_t)out.n_nodes - 1; i >= 0; --i) {
+        uint32_t k = 0, dmax = 1, nmax = 0;
+        for (uint32_t c = 0; c < width; ++c) {
+            const int32_t r = out.slots[(size_t)i * width + c].ref;
+            if (r == kEmpty) continue;
+            ++k;
+            if (r >= 0) { dmax = std::max(dmax, depth[r]); nmax = std::max(nmax, need[r]); }
+        }
+        depth[i] = dmax + 1;
+        need[i] = (k ? k - 1 : 0) + nmax;
+    }
+    out.max_depth = depth[0];
+    out.stack_need = need[0];
+    out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+} // namespace ptrt

@@ -1,0 +1,24 @@
+// bvh_build.h — host-side BVH builder of libptrt (binned SAH BVH2, optional collapse to BVH4),
+// emitting the docs/SPEC.md §4.1 blob. The reference has no acceleration structure.
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+namespace ptrt {
+
+struct BvhSlot { float lo[3]; int32_t ref; float hi[3]; uint32_t aux; };                              // 32 B
+struct BvhTri { float v0[3]; uint32_t id; float e1[3]; uint32_t mat; float e2[3]; uint32_t pad; };    // 48 B
+
+struct BvhBlob {
+    uint32_t width = 0;               // 2 or 4
+    std::vector<BvhSlot> slots;       // n_nodes * width
+    std::vector<BvhTri> tris;         // leaf order
+    uint32_t n_nodes = 0, max_depth = 0, stack_need = 0;
+    float sah_cost = 0.f;
+    double build_ms = 0.0;
+};
+
+// verts9: 9 floats per triangle; mats may be null (all 0). width: 2 or 4.
+void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out);
+
+} // namespace ptrt

@@ -1,0 +1,192 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle on the same seeded inputs and the SAME BVH bytes.
+
+Bars: reference-sphere mode — float within 1e-6 (SURVEY §8c tolerance), RGBA8 within 1 LSB;
+path tracer — ray count identical, image RMSE <= 1e-4 (north_star) — in practice bit-identical.
+"""
+import numpy as np
+import pytest
+
+from test_oracle_reference_kat import check_against_kat
+
+pytestmark = pytest.mark.gpu
+RMSE_TOL = 1e-4  # BASELINE.json north_star: "images within 1e-4 RMSE of the CPU reference"
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)) ** 2)))
+
+
+def run_both(P, pto, r, sd, params, width=4, count=False):
+    r.SetScene(sd, width)
+    r.Params = params
+    if count:
+        r.Params.flags |= P.native.PT_FLAG_COUNT_VISITS
+    st = r.Render(0.0)
+    img = r.ReadFramebuffer()
+    info = r.BvhInfo()
+    osc = pto.Scene(sd, (info.width,) + r.BvhRead())
+    assert osc.validate_bvh()[0] == 0
+    ref, ost = pto.render(osc, params)
+    return img, st, ref, ost
+
+
+def assert_parity(img, st, ref, ost, exact=True):
+    assert st.rays == ost.rays, (st.rays, ost.rays)
+    assert st.paths == ost.paths
+    e = rmse(img, ref)
+    nbad = int((img != ref).any(axis=-1).sum())
+    assert e <= RMSE_TOL, (e, nbad)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    if exact:
+        assert nbad == 0, f"{nbad} pixels differ, rmse {e}"
+
+
+def test_reference_sphere_full_frame(P, pto, renderer):
+    """a1-a4 of SURVEY §8a: the reference's CSMain at its own 1920x1080 (App.cs:27, Renderer.cs:1020)."""
+    renderer.Params = P.make_params(1920, 1080, mode=P.native.PT_REFERENCE_SPHERE)
+    st = renderer.Render(0.0)
+    f, b = renderer.ReadFramebuffer(), renderer.ReadFramebufferRGBA8()
+    check_against_kat(f, b)                       # the reference-pinned known answers
+    of, ob = pto.reference_sphere(1920, 1080)
+    assert np.abs(f - of).max() <= 1e-6
+    assert np.abs(b.astype(int) - ob.astype(int)).max() <= 1
+    assert (f != of).sum() == 0 and (b != ob).sum() == 0, "expected bit-exact: IEEE div/sqrt on both sides"
+    assert st.rays == 1920 * 1080
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (63, 5), (65, 64), (100, 37)])
+def test_reference_sphere_ragged_sizes(P, pto, renderer, w, h):
+    renderer.Params = P.make_params(w, h, mode=P.native.PT_REFERENCE_SPHERE)
+    renderer.Render(0.0)
+    of, ob = pto.reference_sphere(w, h)
+    assert np.array_equal(renderer.ReadFramebuffer(), of) and np.array_equal(renderer.ReadFramebufferRGBA8(), ob)
+
+
+@pytest.mark.parametrize("width", [2, 4])
+def test_c1_cornell(P, pto, renderer, width):
+    """BASELINE config C1: Cornell box, 4 Lambert spheres + area light, 256x256, 4 spp."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL, 0, 0x5EED0001, 256, 256)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(256, 256, spp=4, max_depth=8), width, count=True)
+    assert_parity(img, st, ref, ost)
+    assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests)
+
+
+@pytest.mark.parametrize("width", [2, 4])
+def test_c4_glass_metal_depth16(P, pto, renderer, width):
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, 200, 150)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(200, 150, spp=8, max_depth=16), width)
+    assert_parity(img, st, ref, ost)
+
+
+@pytest.mark.parametrize("width", [2, 4])
+def test_c3_triangle_soup(P, pto, renderer, width):
+    sd = P.make_scene(P.native.PT_SCENE_TRIANGLE_SOUP, 50000, 0x5EED0001, 160, 120)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(160, 120, spp=4, max_depth=8), width, count=True)
+    assert_parity(img, st, ref, ost)
+    assert (st.node_visits, st.tri_tests) == (ost.node_visits, ost.tri_tests)
+
+
+def test_c5_tessellated_cornell(P, pto, renderer):
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_TESS, 60000, 0x5EED0001, 160, 120)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(160, 120, spp=4, max_depth=8), 4)
+    assert_parity(img, st, ref, ost)
+    # free cross-check: tessellated walls are the same surfaces as C2's => same picture up to edge ties
+    sd2 = P.make_scene(P.native.PT_SCENE_CORNELL, 0, 0x5EED0001, 160, 120)
+    img2, _, _, _ = run_both(P, pto, renderer, sd2, P.make_params(160, 120, spp=4, max_depth=8), 4)
+    assert np.mean(np.abs(img[..., :3] - img2[..., :3]) > 1e-3) < 0.02
+
+
+def test_1m_triangles_full_hd_properties(P, pto, renderer):
+    """BASELINE full size (1920x1080, 2^20 triangles): size-independent properties + oracle at reduced spp."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_TESS, 1 << 20, 0x5EED0001, 1920, 1080)
+    renderer.SetScene(sd, 4)
+    renderer.Params = P.make_params(1920, 1080, spp=2, max_depth=8)
+    st = renderer.Render(0.0)
+    img = renderer.ReadFramebuffer()
+    assert np.isfinite(img).all() and (img[..., :3] >= 0).all()
+    assert (img[..., 3] == 1.0).all()                       # every pixel finished exactly spp paths
+    assert st.paths == 1920 * 1080 * 2 and st.paths <= st.rays <= st.paths * 8
+    st2 = renderer.Render(0.0)                              # idempotent / deterministic
+    assert st2.rays == st.rays and np.array_equal(renderer.ReadFramebuffer(), img)
+    info = renderer.BvhInfo()
+    osc = pto.Scene(sd, (info.width,) + renderer.BvhRead())
+    assert osc.validate_bvh()[0] == 0
+    ref, ost = pto.render(osc, renderer.Params)
+    assert ost.rays == st.rays
+    assert rmse(img, ref) <= RMSE_TOL and np.array_equal(img, ref)
+
+
+def test_rank_partition_is_image_invariant(P, pto, renderer):
+    """SPEC §6: the picture must not depend on the number of ranks. Two 'ranks' rendered one after the other on this GPU,
+    concatenated as a gather would, assembled by pt_assemble_tiles == the single-rank frame, bit for bit."""
+    import torch
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 1, 200, 131)
+    renderer.SetScene(sd, 4)
+    renderer.Params = P.make_params(200, 131, spp=3, max_depth=6)
+    one = renderer.Render(0.0)
+    want = renderer.ReadFramebuffer()
+    for nranks in (2, 3, 5):
+        blocks, rays = [], 0
+        for rank in range(nranks):
+            renderer.Params = P.make_params(200, 131, spp=3, max_depth=6, rank=rank, nranks=nranks)
+            st = renderer.Render(0.0)
+            rays += st.rays
+            blocks.append(torch.as_tensor(renderer.TilesDevice(), device="cuda").clone())
+        gathered = torch.cat(blocks)
+        torch.cuda.synchronize()
+        renderer.AssembleTiles(gathered.data_ptr(), gathered.numel())
+        assert rays == one.rays
+        assert np.array_equal(renderer.ReadFramebuffer(), want), nranks
+
+
+def test_edge_cases(P, pto, renderer):
+    N = P.native
+    cam = P.make_scene(0, 0, 0, 70, 40).cam
+    # empty scene: every path is one ray into the sky
+    sd = P.SceneData(cam=cam); sd.sky = np.array([0.25, 0.5, 1.0], np.float32)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(70, 40, spp=2, max_depth=4))
+    assert_parity(img, st, ref, ost) and None
+    assert st.rays == 70 * 40 * 2 and np.allclose(img[..., :3], [0.25, 0.5, 1.0])
+    # one triangle, no spheres; max_depth 1 (camera rays only); spp 1
+    sd = P.SceneData(cam=cam)
+    sd.verts = np.array([[-1, -1, 0, 1, -1, 0, 0, 1, 0]], np.float32); sd.tri_mat = np.zeros(1, np.uint32)
+    m = np.zeros(1, P.MATERIAL_DTYPE); m["albedo"] = 0.5; m["emission"] = (1, 2, 3); sd.mats = m
+    for width in (2, 4):
+        img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(70, 40, spp=1, max_depth=1), width)
+        assert_parity(img, st, ref, ost)
+        assert st.rays == 70 * 40 and img[..., 0].max() == 1.0
+    # spheres only (no BVH nodes at all)
+    sd = P.make_scene(N.PT_SCENE_CORNELL_GLASS, 0, 0, 70, 40); sd.verts = sd.verts[:0]; sd.tri_mat = sd.tri_mat[:0]; sd.sky[:] = 1
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(70, 40, spp=4, max_depth=12))
+    assert_parity(img, st, ref, ost)
+    # sample_offset continues the RNG stream: frame(offset=2, spp=2) equals samples 2,3 of an spp=4 frame
+    sd = P.make_scene(N.PT_SCENE_CORNELL, 0, 0, 70, 40)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(70, 40, spp=2, max_depth=5, sample_offset=2))
+    assert_parity(img, st, ref, ost)
+
+
+def test_errors_raise_like_the_reference(P, renderer):
+    """Every failure is an exception (the reference throws on every Vulkan failure, e.g. Renderer.cs:1022-1025)."""
+    N = P.native
+    sd = P.make_scene(0, 0, 0, 64, 64)
+    renderer.SetScene(sd, 0)
+    for kw in (dict(spp=0), dict(max_depth=0), dict(max_depth=300), dict(ray_eps=float("nan")), dict(mode=7)):
+        renderer.Params = P.make_params(64, 64, **kw)
+        with pytest.raises(P.PtException):
+            renderer.Render(0.0)
+    renderer.Params = P.make_params(64, 64, nranks=2, rank=0)
+    renderer.Render(0.0)
+    with pytest.raises(P.PtException, match="no assembled frame"):
+        renderer.ReadFramebuffer()
+    r2 = P.Renderer(P.Window(64, 64)); r2.Init(); r2.Params = P.make_params(64, 64)
+    with pytest.raises(P.PtException):          # no scene set
+        r2.Render(0.0)
+    r2.Dispose(); r2.Dispose()                  # idempotent, like Dispose(bool) at Renderer.cs:1192
+
+
+def test_app_runs_the_reference_frame(P, pto):
+    """Program.cs:3-7 / App.Run (App.cs:15-21): window 1920x1080, renderer, render loop — one frame of the reference kernel."""
+    with P.App(frames=2) as app:
+        app.Run()
+        b = app.Renderer.ReadFramebufferRGBA8()
+    assert b.shape == (1080, 1920, 4) and int((b[..., 2] > 0).sum()) == 305317
