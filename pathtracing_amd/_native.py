@@ -15,6 +15,17 @@ if not os.path.exists(LIB_PATH):
         "or `python -c 'import __graft_entry__ as g; g.build()'`. libptrt has no CPU fallback."
     )
 
+# One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1; if
+# libptrt.so pulled in /opt/rocm's copy first, a later `import torch` would find two runtimes fighting over the
+# device ("No HIP GPUs are available"). Loading torch first makes the dynamic loader satisfy libptrt's
+# NEEDED libamdhip64.so.7 with the copy that is already mapped (same SONAME), so torch tensors, RCCL and the
+# path tracer share one runtime, one device context and interoperable streams. Hosts without torch (C#, C++)
+# simply get the system runtime.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover - torch is optional plumbing
+    torch = None
+
 lib = C.CDLL(LIB_PATH)
 
 # status codes / enums (ptrt.h)

@@ -183,7 +183,9 @@ class Renderer:
     # Renderer.ComputeFrame (Renderer.cs:1006-1040). `delta` is unused there too.
     def ComputeFrame(self, delta):
         scene = self._scene if self.Params.mode == N.PT_PATH_TRACE else None
-        _check(N.lib.pt_render(self._ctx, scene, C.byref(self.Params), C.byref(self.LastStats)), self._ctx)
+        stats = N.pt_stats()  # a fresh object per frame: callers keep the stats of earlier frames
+        _check(N.lib.pt_render(self._ctx, scene, C.byref(self.Params), C.byref(stats)), self._ctx)
+        self.LastStats = stats
 
     def ReadFramebuffer(self):
         w, h = self.Params.width, self.Params.height

@@ -22,11 +22,9 @@ def _have_gpu():
 
 @pytest.fixture(scope="session", autouse=True)
 def _built():
-    """Build both libraries if they are missing (no-op on the GPU box: the .so files travel with the snapshot)."""
-    need = [os.path.join(ROOT, "pathtracing_amd", "libptrt.so"), os.path.join(ROOT, "oracle", "libpt_oracle.so")]
-    if not all(os.path.exists(p) for p in need):
-        import __graft_entry__ as g
-        g.build()
+    """Make sure both libraries are current with their sources (a stale checker once hid behind an old .so)."""
+    import __graft_entry__ as g
+    g.build()  # `make` is incremental: a no-op when the .so files are newer than their sources
 
 
 @pytest.fixture(scope="session")
