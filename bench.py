@@ -49,6 +49,7 @@ def main():
     import torch
     import torch.distributed as dist
     import pathtracing_amd as P
+    from pathtracing_amd.distributed import gather_tiles
     N = P.native
 
     rank = int(os.environ.get("RANK", "0"))
@@ -76,7 +77,6 @@ def main():
     r.Params = params
     lay = P.tile_layout(params)
     per_rank = lay.tiles_per_rank * lay.floats_per_tile
-    gather_buf = torch.empty(world * per_rank, dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -88,11 +88,10 @@ def main():
         st = r.Render(0.0)  # synchronous: all kernels of this rank's tiles are done on return
         if world > 1:
             mine = torch.as_tensor(r.TilesDevice(), device="cuda")
-            glist = list(gather_buf.split(per_rank)) if rank == 0 else None
-            dist.gather(mine, glist, dst=0)  # the one exchange step: per-tile radiance to rank 0 over xGMI
+            got = gather_tiles(mine, per_rank, rank, world, dist)  # the one exchange step: tile radiance to rank 0 over xGMI
             if rank == 0:
                 torch.cuda.synchronize()
-                r.AssembleTiles(gather_buf.data_ptr(), gather_buf.numel())
+                r.AssembleTiles(got.data_ptr(), got.numel())
         return st
 
     for _ in range(args.warmup):
