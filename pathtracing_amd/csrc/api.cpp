@@ -21,6 +21,7 @@ namespace {
 thread_local std::string g_err;
 
 constexpr uint32_t kLag = 4; // wavefront iterations kept in flight before the host looks at a queue size
+constexpr uint32_t kRingWords = kShards * kCounterStride; // one iteration's readback: the kShards extend-queue sizes
 
 uint32_t host_pcg(uint32_t x)
 {
@@ -54,7 +55,7 @@ struct pt_context {
     DevBuf<float2> hit;
     DevBuf<uint32_t> sd, q_ext0, q_ext1, q_b[B_COUNT], counters, fb8;
     DevBuf<int32_t> stack_ovf;
-    uint32_t *h_counts = nullptr; // pinned: kLag queue sizes + C_COUNT counters
+    uint32_t *h_counts = nullptr; // pinned: kLag readbacks of the per-shard queue sizes + one copy of all counters
     hipEvent_t ev_lag[kLag] = {};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     std::vector<hipEvent_t> ev_pool;
@@ -156,10 +157,10 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
         if (e != hipSuccess) { delete c; return fail(nullptr, PT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
-    bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * (kLag + C_COUNT), hipHostMallocDefault) == hipSuccess;
+    bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * ((size_t)kLag * kRingWords + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess;
     for (uint32_t i = 0; ok && i < kLag; ++i) ok = hipEventCreateWithFlags(&c->ev_lag[i], hipEventDisableTiming) == hipSuccess;
-    ok = ok && c->counters.ensure(C_COUNT) == hipSuccess;
+    ok = ok && c->counters.ensure(kCntTotalWords) == hipSuccess;
     if (!ok) { pt_context_destroy(c); return fail(nullptr, PT_ERR_HIP, "context resource creation failed"); }
     *out = c;
     return PT_OK;
@@ -391,17 +392,20 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
 
     HIP_TRY(c, c->ray_o.ensure(n_slots)); HIP_TRY(c, c->ray_d.ensure(n_slots)); HIP_TRY(c, c->thr.ensure(n_slots));
     HIP_TRY(c, c->acc.ensure(n_slots)); HIP_TRY(c, c->hit.ensure(n_slots)); HIP_TRY(c, c->sd.ensure(n_slots));
-    HIP_TRY(c, c->q_ext0.ensure(n_slots)); HIP_TRY(c, c->q_ext1.ensure(n_slots));
-    for (auto &q : c->q_b) HIP_TRY(c, q.ensure(n_slots));
+    // every queue = kShards regions of shard_cap entries; shard s owns the 256-slot groups g with g % kShards == s
+    const uint32_t groups = n_slots / kBlock, shard_cap = ((groups + kShards - 1) / kShards) * kBlock;
+    const size_t q_entries = (size_t)kShards * shard_cap;
+    HIP_TRY(c, c->q_ext0.ensure(q_entries)); HIP_TRY(c, c->q_ext1.ensure(q_entries));
+    for (auto &q : c->q_b) HIP_TRY(c, q.ensure(q_entries));
     const uint32_t ovf = s->bvh.stack_need > kStackLds ? s->bvh.stack_need - kStackLds : 0u;
-    if (ovf) HIP_TRY(c, c->stack_ovf.ensure((size_t)ovf * n_slots));
+    if (ovf) HIP_TRY(c, c->stack_ovf.ensure((size_t)ovf * q_entries));
     if (nranks == 1) { if ((st = ensure_frame(c, p->width, p->height)) != PT_OK) return st; }
 
     PathState ps{};
     ps.ray_o = c->ray_o.p; ps.ray_d = c->ray_d.p; ps.hit = c->hit.p; ps.thr = c->thr.p; ps.sd = c->sd.p; ps.acc = c->acc.p;
     ps.q_ext[0] = c->q_ext0.p; ps.q_ext[1] = c->q_ext1.p;
     for (uint32_t b = 0; b < B_COUNT; ++b) ps.q_bucket[b] = c->q_b[b].p;
-    ps.counters = c->counters.p; ps.stack_ovf = c->stack_ovf.p; ps.stack_ovf_entries = ovf; ps.n_slots = n_slots;
+    ps.counters = c->counters.p; ps.stack_ovf = c->stack_ovf.p; ps.stack_ovf_entries = ovf; ps.n_slots = n_slots; ps.shard_cap = shard_cap;
 
     FrameParams fp{};
     fp.width = p->width; fp.height = p->height; fp.spp = p->spp; fp.max_depth = p->max_depth; fp.rr_start = p->rr_start;
@@ -410,13 +414,13 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
 
     const DeviceScene &sc = s->ds;
     hipStream_t q = c->stream;
-    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * C_COUNT, q));
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * kCntTotalWords, q));
     HIP_TRY(c, hipEventRecord(c->ev_start, q));
     HIP_TRY(c, launch_generate(q, sc, ps, fp));
 
     // Wavefront loop. The extend queue can only shrink (slots die, none are born), so a queue size read back
     // kLag iterations ago is a valid launch bound: the host never stalls the GPU to size a grid.
-    uint32_t bound = n_slots, iters = 0;
+    uint32_t bound = shard_cap, iters = 0; // per-shard bound: no shard's queue can outgrow the slots it owns
     const uint64_t max_iters = (uint64_t)p->spp * p->max_depth + kLag + 2;
     size_t nev = 0;
     bool done = false;
@@ -434,31 +438,35 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
         HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound));
         if (profile) HIP_TRY(c, hipEventRecord(e2, q));
         const uint32_t ring = iters % kLag;
-        HIP_TRY(c, hipMemcpyAsync(&c->h_counts[ring], c->counters.p + C_EXT0 + (parity ^ 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, q));
+        HIP_TRY(c, hipMemcpyAsync(c->h_counts + (size_t)ring * kRingWords, c->counters.p + cnt_ext_index(parity ^ 1u, 0),
+                                  sizeof(uint32_t) * kRingWords, hipMemcpyDeviceToHost, q));
         HIP_TRY(c, hipEventRecord(c->ev_lag[ring], q));
         ++iters;
         if (iters >= kLag) {
             const uint32_t old = (iters - kLag) % kLag; // iteration iters-kLag: its survivors bound every later queue
             HIP_TRY(c, hipEventSynchronize(c->ev_lag[old]));
-            bound = c->h_counts[old];
+            uint32_t mx = 0; // a shard's queue only shrinks (its slots die, none are born): its old size bounds all later ones
+            for (uint32_t sh = 0; sh < kShards; ++sh) mx = std::max(mx, c->h_counts[(size_t)old * kRingWords + sh * kCounterStride]);
+            bound = mx;
             if (bound == 0) done = true;
         }
     }
     if (nranks == 1)
         HIP_TRY(c, launch_assemble(q, c->acc.p, 1, n_slots, p->width, p->height, lay.tiles_x, lay.n_tiles, 1.0f / (float)p->spp, c->fb.p, c->fb8.p));
     HIP_TRY(c, hipEventRecord(c->ev_stop, q));
-    HIP_TRY(c, hipMemcpyAsync(c->h_counts + kLag, c->counters.p, sizeof(uint32_t) * C_COUNT, hipMemcpyDeviceToHost, q));
+    HIP_TRY(c, hipMemcpyAsync(c->h_counts + (size_t)kLag * kRingWords, c->counters.p, sizeof(uint32_t) * kCntTotalWords, hipMemcpyDeviceToHost, q));
     HIP_TRY(c, hipStreamSynchronize(q));
 
-    const uint32_t *hc = c->h_counts + kLag;
-    if (hc[C_ERROR]) return fail(c, PT_ERR_INTERNAL, "device error flag 0x%x (1 = traversal stack overflow, 2 = step limit)", hc[C_ERROR]);
-    if (hc[C_EXT0] || hc[C_EXT1]) return fail(c, PT_ERR_INTERNAL, "extend queue not empty at frame end");
+    const uint32_t *hc = c->h_counts + (size_t)kLag * kRingWords;
+    if (hc[kCntError]) return fail(c, PT_ERR_INTERNAL, "device error flag 0x%x (1 = traversal stack overflow, 2 = step limit)", hc[kCntError]);
+    auto u64_at = [&](uint32_t w) { return (uint64_t)hc[w] | ((uint64_t)hc[w + 1] << 32); };
+    for (uint32_t sh = 0; sh < kShards; ++sh) {
+        if (hc[cnt_ext_index(0, sh)] || hc[cnt_ext_index(1, sh)]) return fail(c, PT_ERR_INTERNAL, "extend queue of shard %u not empty at frame end", sh);
+        out.rays += u64_at(cnt_rays_index(sh));
+    }
     float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     out.gpu_ms = ms;
-    out.rays = (uint64_t)hc[C_RAYS_LO] | ((uint64_t)hc[C_RAYS_HI] << 32);
-    out.node_visits = (uint64_t)hc[C_NODES_LO] | ((uint64_t)hc[C_NODES_LO + 1] << 32);
-    out.tri_tests = (uint64_t)hc[C_TRIS_LO] | ((uint64_t)hc[C_TRIS_LO + 1] << 32);
-    out.sphere_tests = (uint64_t)hc[C_SPH_LO] | ((uint64_t)hc[C_SPH_LO + 1] << 32);
+    out.node_visits = u64_at(kCntNodes); out.tri_tests = u64_at(kCntTris); out.sphere_tests = u64_at(kCntSph);
     out.iterations = iters; out.extend_launches = iters;
     {   // paths = owned in-image pixels x spp
         uint64_t px = 0;

@@ -1,7 +1,7 @@
 // kernels.hip — gfx950 wavefront kernels of libptrt (docs/SPEC.md; DESIGN.md "Kernels").
 //
 //   k_reference_sphere : the reference's CSMain (Test.hlsl:1-40; dispatch Renderer.cs:1020), one lane = one pixel
-//   k_generate         : camera rays for sample 0 of every owned pixel, fills the extend queue
+//   k_generate         : camera rays for sample 0 of every owned pixel, fills the extend queues
 //   k_extend<N>        : ray -> closest hit. BVH-N traversal, stack in LDS ([level][lane], conflict-free),
 //                        spheres by scalar loads, hits bucketed by material kind with one atomic per wave
 //   k_shade            : emission, BSDF sample, Russian roulette, accumulate, in-place regeneration of the
@@ -10,6 +10,8 @@
 //
 // One slot per owned pixel, at most one live path per slot => framebuffer RMW without atomics and a
 // per-pixel summation order identical to the oracle's `for s in 0..spp`.
+// Queues are split into kShards static shards (ptrt_internal.h): blockIdx.y = shard, and every lane of a block only
+// ever sees slots of its own shard, so a wavefront's push goes to exactly one per-shard counter.
 #include "ptrt_internal.h"
 #include "pt_device.h"
 
@@ -45,12 +47,15 @@ PT_DEV bool slot_pixel(uint32_t slot, const FrameParams &fp, uint32_t &x, uint32
     return x < fp.width && y < fp.height;
 }
 
-PT_DEV Camera load_camera(const pt_camera &c)
+PT_DEV void camera_ray_of(const pt_camera &c, uint32_t x, uint32_t y, uint32_t key, V3 &o, V3 &d)
 {
     Camera k;
-    for (int i = 0; i < 3; ++i) { k.origin[i] = c.origin[i]; k.forward[i] = c.forward[i]; k.right[i] = c.right[i]; k.up[i] = c.up[i]; }
+    k.origin[0] = c.origin[0]; k.origin[1] = c.origin[1]; k.origin[2] = c.origin[2];
+    k.forward[0] = c.forward[0]; k.forward[1] = c.forward[1]; k.forward[2] = c.forward[2];
+    k.right[0] = c.right[0]; k.right[1] = c.right[1]; k.right[2] = c.right[2];
+    k.up[0] = c.up[0]; k.up[1] = c.up[1]; k.up[2] = c.up[2];
     k.scale = c.scale; k.cx = c.cx; k.cy = c.cy; k.jitter = c.jitter;
-    return k;
+    camera_ray(k, x, y, key, o, d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -65,23 +70,26 @@ __global__ void __launch_bounds__(kBlock) k_reference_sphere(uint32_t w, uint32_
 }
 
 // ------------------------------------------------------------------------------------------------
+// grid (shard_cap/256, kShards): entry j of shard s is slot ((j>>8)*kShards + s)*256 + (j&255)
 __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState ps, FrameParams fp)
 {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t shard = blockIdx.y;
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t slot = (((j >> 8) * kShards + shard) << 8) | (j & 255u);
     uint32_t x = 0, y = 0;
-    const bool in_range = slot < ps.n_slots;
+    const bool in_range = j < ps.shard_cap && slot < ps.n_slots;
     const bool valid = in_range && slot_pixel(slot, fp, x, y);
     if (in_range) ps.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) {
         const uint32_t key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset);
         V3 o, d;
-        camera_ray(load_camera(sc.cam), x, y, key, o, d);
+        camera_ray_of(sc.cam, x, y, key, o, d);
         ps.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
         ps.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
         ps.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(key));
         ps.sd[slot] = 0u;
     }
-    wave_push(&ps.counters[C_EXT0], ps.q_ext[0], valid, slot);
+    wave_push(&ps.counters[cnt_ext_index(0, shard)], ps.q_ext[0] + (size_t)shard * ps.shard_cap, valid, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -89,17 +97,20 @@ template <int N, bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_extend(DeviceScene sc, PathState ps, uint32_t parity)
 {
     __shared__ int32_t s_stack[kStackLds * kBlock];
-    const uint32_t n = ps.counters[C_EXT0 + parity];
+    const uint32_t shard = blockIdx.y;
+    const uint32_t n = ps.counters[cnt_ext_index(parity, shard)];
     const uint32_t tid = threadIdx.x;
-    const uint32_t gid = blockIdx.x * kBlock + tid;
+    const uint32_t gid = blockIdx.x * kBlock + tid;          // index inside the shard's queue
     if (gid == 0) {
-        ps.counters[C_EXT0 + (parity ^ 1u)] = 0u; // next iteration's extend queue: filled by k_shade after us
-        unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + C_RAYS_LO);
-        *rays += n;
+        ps.counters[cnt_ext_index(parity ^ 1u, shard)] = 0u;   // next iteration's queue: filled by k_shade after us
+        unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
+        *rays += n;                                            // only this thread ever touches rays[shard]
     }
     if (blockIdx.x * kBlock >= n) return;
     const bool active = gid < n;
-    const uint32_t slot = active ? ps.q_ext[parity][gid] : 0u;
+    const size_t qbase = (size_t)shard * ps.shard_cap;
+    const uint32_t slot = active ? ps.q_ext[parity][qbase + gid] : 0u;
+    const size_t uid = qbase + gid;                            // unique per thread of this launch
 
     Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
     uint32_t bucket = B_MISS;
@@ -117,24 +128,25 @@ __global__ void __launch_bounds__(kBlock) k_extend(DeviceScene sc, PathState ps,
         const RaySetup rs = ray_setup(o, d);
         int32_t cur = sc.n_nodes ? 0 : PT_BVH_EMPTY;
         uint32_t sp = 0, steps = 0;
+        const size_t ovf_stride = (size_t)kShards * ps.shard_cap;
 
         auto push = [&](int32_t v) {
             if (sp < kStackLds) s_stack[sp * kBlock + tid] = v;
             else {
                 const uint32_t e = sp - kStackLds;
-                if (e < ps.stack_ovf_entries) ps.stack_ovf[(size_t)e * ps.n_slots + gid] = v;
-                else { atomicOr(&ps.counters[C_ERROR], 1u); return; }
+                if (e < ps.stack_ovf_entries) ps.stack_ovf[(size_t)e * ovf_stride + uid] = v;
+                else { atomicOr(&ps.counters[kCntError], 1u); return; }
             }
             ++sp;
         };
         auto pop = [&]() -> int32_t {
             if (sp == 0) return PT_BVH_EMPTY;
             --sp;
-            return sp < kStackLds ? s_stack[sp * kBlock + tid] : ps.stack_ovf[(size_t)(sp - kStackLds) * ps.n_slots + gid];
+            return sp < kStackLds ? s_stack[sp * kBlock + tid] : ps.stack_ovf[(size_t)(sp - kStackLds) * ovf_stride + uid];
         };
 
         while (cur != PT_BVH_EMPTY) {
-            if (++steps > (1u << 22)) { atomicOr(&ps.counters[C_ERROR], 2u); break; }
+            if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); break; }
             if (cur >= 0) {
                 const float4 *nd = sc.nodes + (size_t)cur * (2 * N);
                 float4 r[2 * N];
@@ -181,34 +193,34 @@ __global__ void __launch_bounds__(kBlock) k_extend(DeviceScene sc, PathState ps,
             bucket = 1u + __float_as_uint(sc.mats[(size_t)mat * 3].x);
         }
         if (COUNT) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + C_NODES_LO), c_nodes);
-            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + C_TRIS_LO), c_tris);
-            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + C_SPH_LO), c_sph);
+            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
+            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
+            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);
         }
     }
 
-    uint32_t *cb = ps.counters + C_BUCKET0 + parity * B_COUNT;
 #pragma unroll
-    for (uint32_t b = 0; b < B_COUNT; ++b) wave_push(cb + b, ps.q_bucket[b], active && bucket == b, slot);
+    for (uint32_t b = 0; b < B_COUNT; ++b)
+        wave_push(&ps.counters[cnt_bucket_index(parity, b, shard)], ps.q_bucket[b] + qbase, active && bucket == b, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, FrameParams fp, uint32_t parity)
 {
-    const uint32_t *cb = ps.counters + C_BUCKET0 + parity * B_COUNT;
-    const uint32_t c0 = cb[0], c1 = c0 + cb[1], c2 = c1 + cb[2], total = c2 + cb[3];
+    const uint32_t shard = blockIdx.y;
+    const uint32_t c0 = ps.counters[cnt_bucket_index(parity, 0, shard)], c1 = c0 + ps.counters[cnt_bucket_index(parity, 1, shard)],
+                   c2 = c1 + ps.counters[cnt_bucket_index(parity, 2, shard)], total = c2 + ps.counters[cnt_bucket_index(parity, 3, shard)];
     const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
-    if (gid == 0) { // the other parity's buckets were consumed by the previous k_shade; k_extend(i+1) fills them next
-        uint32_t *nb = ps.counters + C_BUCKET0 + (parity ^ 1u) * B_COUNT;
-        nb[0] = 0u; nb[1] = 0u; nb[2] = 0u; nb[3] = 0u;
-    }
+    if (gid < B_COUNT) // the other parity's buckets were consumed by the previous k_shade; k_extend(i+1) fills them next
+        ps.counters[cnt_bucket_index(parity ^ 1u, gid, shard)] = 0u;
     if (blockIdx.x * kBlock >= total) return;
     const bool active = gid < total;
     uint32_t b = B_MISS, qi = gid;
     if (gid >= c2) { b = B_DIELECTRIC; qi = gid - c2; }
     else if (gid >= c1) { b = B_METAL; qi = gid - c1; }
     else if (gid >= c0) { b = B_LAMBERT; qi = gid - c0; }
-    const uint32_t slot = active ? ps.q_bucket[b][qi] : 0u;
+    const size_t qbase = (size_t)shard * ps.shard_cap;
+    const uint32_t slot = active ? ps.q_bucket[b][qbase + qi] : 0u;
     bool alive = false;
 
     if (active) {
@@ -280,7 +292,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
                 uint32_t x = 0, y = 0;
                 slot_pixel(slot, fp, x, y);
                 key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset + sample);
-                camera_ray(load_camera(sc.cam), x, y, key, o, d);
+                camera_ray_of(sc.cam, x, y, key, o, d);
                 T = v3(1.f, 1.f, 1.f);
                 depth = 0;
                 alive = true;
@@ -295,7 +307,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
             ps.sd[slot] = (sample << 8) | depth;
         }
     }
-    wave_push(&ps.counters[C_EXT0 + (parity ^ 1u)], ps.q_ext[parity ^ 1u], alive, slot);
+    wave_push(&ps.counters[cnt_ext_index(parity ^ 1u, shard)], ps.q_ext[parity ^ 1u] + qbase, alive, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -331,13 +343,13 @@ hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4
 
 hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp)
 {
-    hipLaunchKernelGGL(k_generate, dim3(blocks_for(ps.n_slots)), dim3(kBlock), 0, s, sc, ps, fp);
+    hipLaunchKernelGGL(k_generate, dim3(blocks_for(ps.shard_cap), kShards), dim3(kBlock), 0, s, sc, ps, fp);
     return hipGetLastError();
 }
 
-hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t n_bound, bool count)
+hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count)
 {
-    const dim3 grid(blocks_for(n_bound)), block(kBlock);
+    const dim3 grid(blocks_for(shard_bound), kShards), block(kBlock);
     if (sc.bvh_width == 4) {
         if (count) hipLaunchKernelGGL((k_extend<4, true>), grid, block, 0, s, sc, ps, parity);
         else hipLaunchKernelGGL((k_extend<4, false>), grid, block, 0, s, sc, ps, parity);
@@ -348,9 +360,9 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
     return hipGetLastError();
 }
 
-hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t n_bound)
+hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound)
 {
-    hipLaunchKernelGGL(k_shade, dim3(blocks_for(n_bound)), dim3(kBlock), 0, s, sc, ps, fp, parity);
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(shard_bound), kShards), dim3(kBlock), 0, s, sc, ps, fp, parity);
     return hipGetLastError();
 }
 

@@ -13,16 +13,31 @@ constexpr uint32_t kBlock = 256;                   // threads per workgroup = 4 
 constexpr uint32_t kStackLds = 24;                 // traversal-stack entries kept in LDS per lane
 constexpr uint32_t kMaxSpheres = 64;
 
-// counters block in device memory (uint32 unless noted)
-enum Counter : uint32_t {
-    C_EXT0 = 0, C_EXT1 = 1,          // extend-queue sizes, by iteration parity
-    C_BUCKET0 = 2,                   // 2 parities x 4 buckets: C_BUCKET0 + parity*4 + bucket
-    C_ERROR = 10,                    // sticky device-side error flag
-    C_RAYS_LO = 12, C_RAYS_HI = 13,  // u64 total extend-queue entries processed
-    C_NODES_LO = 14, C_TRIS_LO = 16, C_SPH_LO = 18, // u64 visit counters (COUNT builds)
-    C_COUNT = 32
-};
+// Queue sharding. A slot belongs to shard (slot >> 8) % kShards for the whole frame, every queue is kShards
+// independent regions of `shard_cap` entries with one counter each, and blockIdx.y selects the shard in every kernel.
+// Why: a queue push is one returning atomic per wavefront; on ONE address that saturates at ~88 atomics/us
+// (MI355X_MICROARCH.md "dequeue"), which made both wavefront kernels atomic-bound (~230 us per launch regardless of
+// the scene). 64 counters on 64 separate lines take the same pushes at ~64x the rate.
+constexpr uint32_t kShards = 64;
+constexpr uint32_t kCounterStride = 16;            // u32 words between counters: one 64-B line each
+
 enum Bucket : uint32_t { B_MISS = 0, B_LAMBERT = 1, B_METAL = 2, B_DIELECTRIC = 3, B_COUNT = 4 };
+
+// counters block (u32 words). ext[parity][shard], bucket[parity][bucket][shard], rays[shard] (u64), then globals.
+constexpr uint32_t kCntExt = 0;
+constexpr uint32_t kCntBucket = kCntExt + 2 * kShards * kCounterStride;
+constexpr uint32_t kCntRays = kCntBucket + 2 * B_COUNT * kShards * kCounterStride;
+constexpr uint32_t kCntGlobals = kCntRays + kShards * kCounterStride;
+constexpr uint32_t kCntError = kCntGlobals + 0;
+constexpr uint32_t kCntNodes = kCntGlobals + 2, kCntTris = kCntGlobals + 4, kCntSph = kCntGlobals + 6; // u64 each
+constexpr uint32_t kCntTotalWords = kCntGlobals + 16;
+
+inline __host__ __device__ uint32_t cnt_ext_index(uint32_t parity, uint32_t shard) { return kCntExt + (parity * kShards + shard) * kCounterStride; }
+inline __host__ __device__ uint32_t cnt_bucket_index(uint32_t parity, uint32_t bucket, uint32_t shard)
+{
+    return kCntBucket + ((parity * B_COUNT + bucket) * kShards + shard) * kCounterStride;
+}
+inline __host__ __device__ uint32_t cnt_rays_index(uint32_t shard) { return kCntRays + shard * kCounterStride; }
 
 struct DeviceScene {
     const float4 *nodes;   // BVH-N: node i slot c = rows (i*N + c)*2 + {0: lo.xyz|ref, 1: hi.xyz|0}
@@ -43,12 +58,13 @@ struct PathState {           // SoA over slots
     float4 *thr;             // T.rgb, key bits
     uint32_t *sd;            // sample << 8 | depth
     float4 *acc;             // radiance sum rgb, path count
-    uint32_t *q_ext[2];      // extend queues (slot ids), by parity
-    uint32_t *q_bucket[B_COUNT];
+    uint32_t *q_ext[2];      // extend queues (slot ids) [shard][shard_cap], by iteration parity
+    uint32_t *q_bucket[B_COUNT]; // shade queues per material kind, [shard][shard_cap]
     uint32_t *counters;
-    int32_t *stack_ovf;      // traversal stack overflow, [entry][slot]
+    int32_t *stack_ovf;      // traversal stack overflow, [entry][kShards * shard_cap]
     uint32_t stack_ovf_entries;
     uint32_t n_slots;
+    uint32_t shard_cap;      // entries per shard region = slots owned by a shard (multiple of 256)
 };
 
 struct FrameParams {
@@ -58,10 +74,11 @@ struct FrameParams {
 };
 
 // kernel launchers (kernels.hip). All enqueue on `s` and return the launch error.
+// `shard_bound` = upper bound of any shard's queue length for this launch.
 hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4 *out_f, uint32_t *out_rgba8);
 hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp);
-hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t n_bound, bool count);
-hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t n_bound);
+hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count);
+hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound);
 hipError_t launch_assemble(hipStream_t s, const float4 *gathered, uint32_t nranks, uint32_t slots_per_rank,
                            uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, float inv_spp,
                            float4 *fb, uint32_t *fb8);
