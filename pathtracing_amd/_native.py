@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptrt.so")
+LIB_PATH = os.environ.get("PTRT_LIB") or os.path.join(_HERE, "libptrt.so")  # PTRT_LIB: developer aid for A/B-ing kernel builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -73,7 +73,8 @@ struct pt_scene {
     float sky[3] = { 0.f, 0.f, 0.f };
     bool have_cam = false, committed = false;
     BvhBlob bvh;
-    DevBuf<float4> d_nodes, d_tris, d_spheres, d_mats;
+    DevBuf<float4> d_nodes, d_tris, d_tri_shade, d_spheres, d_mats;
+    bool has_specular = false;
     DevBuf<uint32_t> d_sph_mat;
     DeviceScene ds{};
 };
@@ -201,7 +202,7 @@ void pt_scene_destroy(pt_scene *s)
 {
     if (!s) return;
     if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
-    s->d_nodes.release(); s->d_tris.release(); s->d_spheres.release(); s->d_mats.release(); s->d_sph_mat.release();
+    s->d_nodes.release(); s->d_tris.release(); s->d_tri_shade.release(); s->d_spheres.release(); s->d_mats.release(); s->d_sph_mat.release();
     delete s;
 }
 
@@ -287,6 +288,20 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     static_assert(sizeof(BvhSlot) == 32 && sizeof(BvhTri) == 48 && sizeof(pt_material) == 48, "blob layout");
     HIP_TRY(c, s->d_nodes.ensure(s->bvh.slots.size() * 2));
     HIP_TRY(c, s->d_tris.ensure(s->bvh.tris.size() * 3));
+    HIP_TRY(c, s->d_tri_shade.ensure(s->bvh.tris.size()));
+    {   // per-triangle shading record: ng = normalize(cross(e1,e2)) in exactly the op order of docs/SPEC.md §0 (fma, IEEE
+        // sqrt and divide), so the bits equal what the kernel would compute from e1,e2; 16 B instead of two 16-B rows.
+        std::vector<float> ts(s->bvh.tris.size() * 4);
+        for (size_t i = 0; i < s->bvh.tris.size(); ++i) {
+            const BvhTri &t = s->bvh.tris[i];
+            const float *a = t.e1, *b = t.e2;
+            const float cx = std::fmaf(a[1], b[2], -(a[2] * b[1])), cy = std::fmaf(a[2], b[0], -(a[0] * b[2])), cz = std::fmaf(a[0], b[1], -(a[1] * b[0]));
+            const float inv = 1.0f / std::sqrt(std::fmaf(cz, cz, std::fmaf(cy, cy, cx * cx)));
+            ts[i * 4 + 0] = cx * inv; ts[i * 4 + 1] = cy * inv; ts[i * 4 + 2] = cz * inv;
+            std::memcpy(&ts[i * 4 + 3], &t.mat, 4);
+        }
+        if (!ts.empty()) HIP_TRY(c, hipMemcpy(s->d_tri_shade.p, ts.data(), ts.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, s->d_spheres.ensure(ns));
     HIP_TRY(c, s->d_sph_mat.ensure(ns));
     HIP_TRY(c, s->d_mats.ensure((size_t)nm * 3));
@@ -299,11 +314,13 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     if (nm) HIP_TRY(c, hipMemcpy(s->d_mats.p, s->mats.data(), (size_t)nm * sizeof(pt_material), hipMemcpyHostToDevice));
 
     DeviceScene &d = s->ds;
-    d.nodes = s->d_nodes.p; d.tris = s->d_tris.p; d.spheres = s->d_spheres.p; d.sph_mat = s->d_sph_mat.p; d.mats = s->d_mats.p;
+    d.nodes = s->d_nodes.p; d.tris = s->d_tris.p; d.tri_shade = s->d_tri_shade.p; d.spheres = s->d_spheres.p; d.sph_mat = s->d_sph_mat.p; d.mats = s->d_mats.p;
     d.n_nodes = s->bvh.n_nodes; d.n_tris = nt; d.n_spheres = ns; d.n_mats = nm;
     for (int k = 0; k < 3; ++k) d.sky[k] = s->sky[k];
     d.bvh_width = bvh_width;
     d.cam = s->cam;
+    s->has_specular = false;
+    for (const pt_material &m : s->mats) if (m.kind != PT_LAMBERT) s->has_specular = true;
     s->committed = true;
     return PT_OK;
 }
@@ -435,7 +452,8 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
         }
         HIP_TRY(c, launch_extend(q, sc, ps, parity, bound, count));
         if (profile) HIP_TRY(c, hipEventRecord(e1, q));
-        HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound));
+        HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound, false));
+        if (s->has_specular) HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound, true)); // metal + dielectric buckets
         if (profile) HIP_TRY(c, hipEventRecord(e2, q));
         const uint32_t ring = iters % kLag;
         HIP_TRY(c, hipMemcpyAsync(c->h_counts + (size_t)ring * kRingWords, c->counters.p + cnt_ext_index(parity ^ 1u, 0),

@@ -14,6 +14,11 @@
 // ever sees slots of its own shard, so a wavefront's push goes to exactly one per-shard counter.
 #include "ptrt_internal.h"
 #include "pt_device.h"
+#include <cstdlib>
+
+#ifndef PT_EXT_CHUNK_DEFAULT
+#define PT_EXT_CHUNK_DEFAULT 0
+#endif
 
 using namespace ptd;
 
@@ -94,26 +99,25 @@ __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState p
 
 // ------------------------------------------------------------------------------------------------
 template <int N, bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_extend(DeviceScene sc, PathState ps, uint32_t parity)
+__global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState ps, uint32_t parity)
 {
-    __shared__ int32_t s_stack[kStackLds * kBlock];
+    __shared__ int32_t s_stack[kStackLds * kExtBlock];
     const uint32_t shard = blockIdx.y;
     const uint32_t n = ps.counters[cnt_ext_index(parity, shard)];
     const uint32_t tid = threadIdx.x;
-    const uint32_t gid = blockIdx.x * kBlock + tid;          // index inside the shard's queue
+    const uint32_t gid = blockIdx.x * kExtBlock + tid;          // index inside the shard's queue
     if (gid == 0) {
         ps.counters[cnt_ext_index(parity ^ 1u, shard)] = 0u;   // next iteration's queue: filled by k_shade after us
         unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
         *rays += n;                                            // only this thread ever touches rays[shard]
     }
-    if (blockIdx.x * kBlock >= n) return;
+    if (blockIdx.x * kExtBlock >= n) return;
     const bool active = gid < n;
     const size_t qbase = (size_t)shard * ps.shard_cap;
     const uint32_t slot = active ? ps.q_ext[parity][qbase + gid] : 0u;
     const size_t uid = qbase + gid;                            // unique per thread of this launch
 
     Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
-    uint32_t bucket = B_MISS;
     unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0;
 
     if (active) {
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(kBlock) k_extend(DeviceScene sc, PathState ps,
         const size_t ovf_stride = (size_t)kShards * ps.shard_cap;
 
         auto push = [&](int32_t v) {
-            if (sp < kStackLds) s_stack[sp * kBlock + tid] = v;
+            if (sp < kStackLds) s_stack[sp * kExtBlock + tid] = v;
             else {
                 const uint32_t e = sp - kStackLds;
                 if (e < ps.stack_ovf_entries) ps.stack_ovf[(size_t)e * ovf_stride + uid] = v;
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(kBlock) k_extend(DeviceScene sc, PathState ps,
         auto pop = [&]() -> int32_t {
             if (sp == 0) return PT_BVH_EMPTY;
             --sp;
-            return sp < kStackLds ? s_stack[sp * kBlock + tid] : ps.stack_ovf[(size_t)(sp - kStackLds) * ovf_stride + uid];
+            return sp < kStackLds ? s_stack[sp * kExtBlock + tid] : ps.stack_ovf[(size_t)(sp - kStackLds) * ovf_stride + uid];
         };
 
         while (cur != PT_BVH_EMPTY) {
@@ -186,42 +190,184 @@ __global__ void __launch_bounds__(kBlock) k_extend(DeviceScene sc, PathState ps,
             }
         }
 
-        ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref));
-        if (h.ref != PT_MISS) {
-            const uint32_t mat = h.ref < sc.n_tris ? __float_as_uint(sc.tris[(size_t)h.ref * 3 + 1].w)
-                                                   : sc.sph_mat[h.ref - sc.n_tris];
-            bucket = 1u + __float_as_uint(sc.mats[(size_t)mat * 3].x);
-        }
+        ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref)); // k_shade<false> walks the same queue in the same order
         if (COUNT) {
             atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
             atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
             atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);
         }
     }
-
-#pragma unroll
-    for (uint32_t b = 0; b < B_COUNT; ++b)
-        wave_push(&ps.counters[cnt_bucket_index(parity, b, shard)], ps.q_bucket[b] + qbase, active && bucket == b, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_extend_packed: same per-ray work and the same per-ray traversal order as k_extend (so hits AND visit counters
+// are identical), but a wavefront owns `chunk` consecutive queue entries instead of 64 and keeps its lanes packed:
+// whenever >= kRefillIdle lanes have finished their ray (ballot + popcount), the finished lanes retire (hit record,
+// bucket push) and idle lanes pull the next entries of the chunk by mbcnt prefix. With one ray per lane a wave runs
+// as long as its slowest ray (measured 19 % lane utilisation on the 1M-triangle soup); with refill the wave's time
+// tends to the chunk's mean. No atomics and no cross-wave traffic are added: the chunk is private to the wave.
+#ifndef PT_REFILL_IDLE
+#define PT_REFILL_IDLE 16
+#endif
+constexpr uint32_t kRefillIdle = PT_REFILL_IDLE;
+
+template <int N, bool COUNT>
+__global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState ps, uint32_t parity, uint32_t chunk)
+{
+    __shared__ int32_t s_stack[kStackLds * 64];
+    const uint32_t shard = blockIdx.y;
+    const uint32_t n = ps.counters[cnt_ext_index(parity, shard)];
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x == 0 && lane == 0) {
+        ps.counters[cnt_ext_index(parity ^ 1u, shard)] = 0u;
+        unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
+        *rays += n;
+    }
+    uint32_t next = blockIdx.x * chunk;                        // wave-uniform cursor into the shard's queue
+    if (next >= n) return;
+    const uint32_t end = min(n, next + chunk);
+    const size_t qbase = (size_t)shard * ps.shard_cap;
+    const uint32_t *queue = ps.q_ext[parity] + qbase;
+    const size_t uid = qbase + (size_t)blockIdx.x * 64u + lane; // unique per thread of this launch (chunk >= 64)
+    const size_t ovf_stride = (size_t)kShards * ps.shard_cap;
+
+    bool has = false;                                          // lane holds a ray
+    uint32_t slot = 0, sp = 0, steps = 0;
+    int32_t cur = PT_BVH_EMPTY;
+    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
+    RaySetup rs = ray_setup(o, d);
+    Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
+    unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0;
+
+    auto push = [&](int32_t v) {
+        if (sp < kStackLds) s_stack[sp * 64u + lane] = v;
+        else {
+            const uint32_t e = sp - kStackLds;
+            if (e < ps.stack_ovf_entries) ps.stack_ovf[(size_t)e * ovf_stride + uid] = v;
+            else { atomicOr(&ps.counters[kCntError], 1u); return; }
+        }
+        ++sp;
+    };
+    auto pop = [&]() -> int32_t {
+        if (sp == 0) return PT_BVH_EMPTY;
+        --sp;
+        return sp < kStackLds ? s_stack[sp * 64u + lane] : ps.stack_ovf[(size_t)(sp - kStackLds) * ovf_stride + uid];
+    };
+
+    for (;;) {
+        // ---- retire finished rays (wave-uniform point)
+        const bool fin = has && cur == PT_BVH_EMPTY;
+        if (fin) {
+            ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref));
+            has = false;
+        }
+        // ---- refill idle lanes from the wave's chunk
+        const uint64_t idle = __ballot(!has);
+        const uint32_t avail = end - next;
+        if (idle && avail) {
+            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (!has && prefix < avail) {
+                slot = queue[next + prefix];
+                const float4 O = ps.ray_o[slot], D = ps.ray_d[slot];
+                o = xyz(O); d = xyz(D);
+                h = Hit{ __builtin_inff(), PT_MISS, PT_MISS };
+                for (uint32_t j = 0; j < sc.n_spheres; ++j) {
+                    sphere_test(sc.spheres[j], sc.n_tris + j, o, d, h);
+                    if (COUNT) c_sph++;
+                }
+                rs = ray_setup(o, d);
+                cur = sc.n_nodes ? 0 : PT_BVH_EMPTY;
+                sp = 0; steps = 0;
+                has = true;
+            }
+            next += min((uint32_t)__popcll(idle), avail);
+        }
+        if (!__ballot(has)) break;
+        // ---- traverse until enough lanes went idle to make a refill worth its latency (or nothing is left to pull)
+        const uint32_t want = (next < end) ? kRefillIdle : 64u;
+        for (;;) {
+            if (cur != PT_BVH_EMPTY) {
+                if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; }
+                else if (cur >= 0) {
+                    const float4 *nd = sc.nodes + (size_t)cur * (2 * N);
+                    float4 r[2 * N];
+#pragma unroll
+                    for (int i = 0; i < 2 * N; ++i) r[i] = nd[i];
+                    if (COUNT) c_nodes++;
+                    uint32_t key[N];
+                    int32_t ref[N];
+#pragma unroll
+                    for (int c = 0; c < N; ++c) {
+                        float tn;
+                        ref[c] = __float_as_int(r[2 * c].w);
+                        const bool hb = box_test(r[2 * c], r[2 * c + 1], rs, h.t, tn) && ref[c] != PT_BVH_EMPTY;
+                        key[c] = hb ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+                    }
+                    auto cswap = [&](int a, int b) {
+                        if (key[a] > key[b]) {
+                            const uint32_t tk = key[a]; key[a] = key[b]; key[b] = tk;
+                            const int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
+                        }
+                    };
+                    if (N == 2) { cswap(0, 1); }
+                    else { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); }
+#pragma unroll
+                    for (int i = N - 1; i >= 1; --i)
+                        if (key[i] != 0xFFFFFFFFu) push(ref[i]);
+                    cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop();
+                } else {
+                    const uint32_t enc = (uint32_t)~cur, first = enc >> 3, cnt = (enc & 7u) + 1u;
+                    for (uint32_t j = 0; j < cnt; ++j) {
+                        const uint32_t idx = first + j;
+                        const float4 *tp = sc.tris + (size_t)idx * 3;
+                        tri_test(tp[0], tp[1], tp[2], idx, o, d, h);
+                        if (COUNT) c_tris++;
+                    }
+                    cur = pop();
+                }
+            }
+            const uint32_t busy = (uint32_t)__popcll(__ballot(has && cur != PT_BVH_EMPTY));
+            if (busy == 0u || 64u - busy >= want) break;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
+        atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
+        atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade<false>: walks the extend queue of this iteration in the SAME order k_extend did, so ray/throughput/hit
+//                 reads are the coalesced, L2-warm lines k_extend just touched. Misses and Lambert hits are shaded
+//                 in place; the rare specular kinds (metal, dielectric) are deferred to per-kind bucket queues so that
+//                 their long BSDF code never runs in a wave of diffuse lanes.
+// k_shade<true> : walks the two specular buckets, concatenated, so the kind switch is wave-uniform.
+template <bool SPEC>
 __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, FrameParams fp, uint32_t parity)
 {
     const uint32_t shard = blockIdx.y;
-    const uint32_t c0 = ps.counters[cnt_bucket_index(parity, 0, shard)], c1 = c0 + ps.counters[cnt_bucket_index(parity, 1, shard)],
-                   c2 = c1 + ps.counters[cnt_bucket_index(parity, 2, shard)], total = c2 + ps.counters[cnt_bucket_index(parity, 3, shard)];
     const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
-    if (gid < B_COUNT) // the other parity's buckets were consumed by the previous k_shade; k_extend(i+1) fills them next
-        ps.counters[cnt_bucket_index(parity ^ 1u, gid, shard)] = 0u;
-    if (blockIdx.x * kBlock >= total) return;
-    const bool active = gid < total;
-    uint32_t b = B_MISS, qi = gid;
-    if (gid >= c2) { b = B_DIELECTRIC; qi = gid - c2; }
-    else if (gid >= c1) { b = B_METAL; qi = gid - c1; }
-    else if (gid >= c0) { b = B_LAMBERT; qi = gid - c0; }
     const size_t qbase = (size_t)shard * ps.shard_cap;
-    const uint32_t slot = active ? ps.q_bucket[b][qbase + qi] : 0u;
+    uint32_t total, b = B_LAMBERT, slot = 0u;
+    bool active;
+    if (SPEC) {
+        const uint32_t c0 = ps.counters[cnt_bucket_index(parity, B_METAL, shard)];
+        total = c0 + ps.counters[cnt_bucket_index(parity, B_DIELECTRIC, shard)];
+        if (gid < 2u) // the other parity's buckets were consumed by the previous k_shade<true>; k_shade<false>(i+1) fills them
+            ps.counters[cnt_bucket_index(parity ^ 1u, B_METAL + gid, shard)] = 0u;
+        if (blockIdx.x * kBlock >= total) return;
+        active = gid < total;
+        b = gid >= c0 ? B_DIELECTRIC : B_METAL;
+        if (active) slot = ps.q_bucket[b][qbase + (gid >= c0 ? gid - c0 : gid)];
+    } else {
+        total = ps.counters[cnt_ext_index(parity, shard)];
+        if (blockIdx.x * kBlock >= total) return;
+        active = gid < total;
+        if (active) slot = ps.q_ext[parity][qbase + gid];
+    }
     bool alive = false;
+    uint32_t defer = 0u; // SPEC == false: bucket this lane's hit must be shaded in (0 = handled here)
 
     if (active) {
         const float2 hr = ps.hit[slot];
@@ -238,7 +384,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
             A.x = fma_(T.x, L.x, A.x); A.y = fma_(T.y, L.y, A.y); A.z = fma_(T.z, L.z, A.z);
         };
 
-        if (b == B_MISS) {
+        if (ref == PT_MISS) {
             add(v3(sc.sky[0], sc.sky[1], sc.sky[2]));
             term = true;
         } else {
@@ -246,9 +392,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
             V3 ng;
             uint32_t mat;
             if (ref < sc.n_tris) {
-                const float4 r1 = sc.tris[(size_t)ref * 3 + 1], r2 = sc.tris[(size_t)ref * 3 + 2];
-                ng = normalize(cross(xyz(r1), xyz(r2)));
-                mat = __float_as_uint(r1.w);
+                const float4 ts = sc.tri_shade[ref]; // normalize(cross(e1,e2)) precomputed at commit, bit-identical
+                ng = xyz(ts);
+                mat = __float_as_uint(ts.w);
             } else {
                 const uint32_t j = ref - sc.n_tris;
                 const float4 s = sc.spheres[j];
@@ -260,6 +406,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
             const V3 n = front ? ng : neg(ng);
             const float4 m0 = sc.mats[(size_t)mat * 3], m1 = sc.mats[(size_t)mat * 3 + 1], m2 = sc.mats[(size_t)mat * 3 + 2];
             const V3 alb = v3(m0.y, m0.z, m0.w), emi = xyz(m1);
+            const uint32_t kind = __float_as_uint(m0.x);
+            if (!SPEC && kind != (uint32_t)PT_LAMBERT) defer = 1u + kind; // shaded by k_shade<true>; this lane leaves everything untouched
+            else {
             if (emi.x != 0.0f || emi.y != 0.0f || emi.z != 0.0f) add(emi);
             if (depth >= fp.max_depth) term = true;
             else {
@@ -267,7 +416,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
                 V3 wi = d, W = v3(1.f, 1.f, 1.f);
                 float side = 1.0f;
                 bool ok = true;
-                if (b == B_LAMBERT) sample_lambert(alb, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
+                if (!SPEC) sample_lambert(alb, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
                 else if (b == B_METAL) ok = sample_metal(alb, m1.w, d, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
                 else sample_dielectric(alb, m2.x, d, n, front, u01(key, 6u + 4u * bb), wi, W, side);
                 if (!ok) term = true;
@@ -282,9 +431,12 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
                     if (!term) { o = madd(side * fp.ray_eps, n, P); d = wi; }
                 }
             }
+            }
         }
 
-        if (term) {
+        if (defer) {
+            // nothing: the path state stays as k_extend left it
+        } else if (term) {
             if (!touched) { A = ps.acc[slot]; touched = true; }
             A.w += 1.0f;
             ++sample;
@@ -308,6 +460,10 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
         }
     }
     wave_push(&ps.counters[cnt_ext_index(parity ^ 1u, shard)], ps.q_ext[parity ^ 1u] + qbase, alive, slot);
+    if (!SPEC) {
+        wave_push(&ps.counters[cnt_bucket_index(parity, B_METAL, shard)], ps.q_bucket[B_METAL] + qbase, defer == B_METAL, slot);
+        wave_push(&ps.counters[cnt_bucket_index(parity, B_DIELECTRIC, shard)], ps.q_bucket[B_DIELECTRIC] + qbase, defer == B_DIELECTRIC, slot);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -349,7 +505,24 @@ hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState
 
 hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count)
 {
-    const dim3 grid(blocks_for(shard_bound), kShards), block(kBlock);
+    // Rays per wavefront of the packed kernel; 0 selects the one-ray-per-lane kernel. PTRT_EXT_CHUNK overrides (A/B aid).
+    static const uint32_t chunk_cfg = [] {
+        const char *e = getenv("PTRT_EXT_CHUNK");
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : (uint32_t)PT_EXT_CHUNK_DEFAULT;
+    }();
+    if (chunk_cfg >= 64u) {
+        const uint32_t chunk = chunk_cfg;
+        const dim3 pgrid(shard_bound ? (shard_bound + chunk - 1) / chunk : 1u, kShards), pblock(64);
+        if (sc.bvh_width == 4) {
+            if (count) hipLaunchKernelGGL((k_extend_packed<4, true>), pgrid, pblock, 0, s, sc, ps, parity, chunk);
+            else hipLaunchKernelGGL((k_extend_packed<4, false>), pgrid, pblock, 0, s, sc, ps, parity, chunk);
+        } else {
+            if (count) hipLaunchKernelGGL((k_extend_packed<2, true>), pgrid, pblock, 0, s, sc, ps, parity, chunk);
+            else hipLaunchKernelGGL((k_extend_packed<2, false>), pgrid, pblock, 0, s, sc, ps, parity, chunk);
+        }
+        return hipGetLastError();
+    }
+    const dim3 grid(shard_bound ? (shard_bound + kExtBlock - 1) / kExtBlock : 1u, kShards), block(kExtBlock);
     if (sc.bvh_width == 4) {
         if (count) hipLaunchKernelGGL((k_extend<4, true>), grid, block, 0, s, sc, ps, parity);
         else hipLaunchKernelGGL((k_extend<4, false>), grid, block, 0, s, sc, ps, parity);
@@ -360,9 +533,11 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
     return hipGetLastError();
 }
 
-hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound)
+hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, bool specular)
 {
-    hipLaunchKernelGGL(k_shade, dim3(blocks_for(shard_bound), kShards), dim3(kBlock), 0, s, sc, ps, fp, parity);
+    const dim3 grid(blocks_for(shard_bound), kShards), block(kBlock);
+    if (specular) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, sc, ps, fp, parity);
+    else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, sc, ps, fp, parity);
     return hipGetLastError();
 }
 

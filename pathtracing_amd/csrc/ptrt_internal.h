@@ -10,7 +10,14 @@ constexpr uint32_t kTileShift = 6;                 // 64x64 tiles (docs/SPEC.md 
 constexpr uint32_t kTile = 1u << kTileShift;
 constexpr uint32_t kTilePixels = kTile * kTile;
 constexpr uint32_t kBlock = 256;                   // threads per workgroup = 4 wavefronts
-constexpr uint32_t kStackLds = 24;                 // traversal-stack entries kept in LDS per lane
+#ifndef PT_STACK_LDS
+#define PT_STACK_LDS 24
+#endif
+#ifndef PT_EXT_BLOCK
+#define PT_EXT_BLOCK 64
+#endif
+constexpr uint32_t kStackLds = PT_STACK_LDS;       // traversal-stack entries kept in LDS per lane
+constexpr uint32_t kExtBlock = PT_EXT_BLOCK;       // workgroup size of k_extend (a wave retires on its own when it is 64)
 constexpr uint32_t kMaxSpheres = 64;
 
 // Queue sharding. A slot belongs to shard (slot >> 8) % kShards for the whole frame, every queue is kShards
@@ -42,6 +49,7 @@ inline __host__ __device__ uint32_t cnt_rays_index(uint32_t shard) { return kCnt
 struct DeviceScene {
     const float4 *nodes;   // BVH-N: node i slot c = rows (i*N + c)*2 + {0: lo.xyz|ref, 1: hi.xyz|0}
     const float4 *tris;    // 3 rows per triangle: v0|orig_id, e1|material, e2|0
+    const float4 *tri_shade; // per triangle (blob order): geometric normal normalize(cross(e1,e2)) | material
     const float4 *spheres; // cx,cy,cz,r
     const uint32_t *sph_mat;
     const float4 *mats;    // 3 rows per material (48 B pt_material)
@@ -78,7 +86,7 @@ struct FrameParams {
 hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4 *out_f, uint32_t *out_rgba8);
 hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp);
 hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count);
-hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound);
+hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, bool specular);
 hipError_t launch_assemble(hipStream_t s, const float4 *gathered, uint32_t nranks, uint32_t slots_per_rank,
                            uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, float inv_spp,
                            float4 *fb, uint32_t *fb8);
