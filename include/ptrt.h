@@ -55,10 +55,16 @@ enum { PT_LAMBERT = 0, PT_METAL = 1, PT_DIELECTRIC = 2 };
 /* pt_render_params.flags */
 enum {
     PT_FLAG_PROFILE_KERNELS = 1u, /* bracket every kernel with HIP events on the context's stream; fills pt_stats.*_ms */
-    PT_FLAG_COUNT_VISITS = 2u     /* count BVH node visits / triangle / sphere tests on the device (slower build of extend) */
+    PT_FLAG_COUNT_VISITS = 2u,    /* count BVH node visits / triangle / sphere tests on the device (slower build of extend) */
+    PT_FLAG_EXTEND_PACKED = 4u    /* lane-packing extend kernel: a wavefront owns 128 queue entries and refills idle lanes by ballot */
 };
 /* pt_scene_commit options */
-enum { PT_BVH_WIDTH_DEFAULT = 0, PT_BVH_WIDTH_2 = 2, PT_BVH_WIDTH_4 = 4 };
+enum {
+    PT_BVH_WIDTH_DEFAULT = 0, /* = PT_BVH_WIDTH_4Q */
+    PT_BVH_WIDTH_2 = 2,       /* binary, 64-B nodes, f32 child boxes */
+    PT_BVH_WIDTH_4 = 4,       /* 4-wide, 128-B nodes, f32 child boxes */
+    PT_BVH_WIDTH_4Q = 68      /* 4-wide, 64-B nodes, child boxes quantised to 8 bits on a per-node power-of-two grid */
+};
 
 typedef struct {
     int32_t device_ordinal; /* hipSetDevice argument; the reference picks its device in GraphicsDevice.cs:38-43 */
@@ -86,7 +92,10 @@ typedef struct {
     uint32_t rank, nranks;   /* image-space partition: this process renders tiles t with t % nranks == rank */
     uint32_t tile_size;      /* 0 = 64 */
     uint32_t flags;          /* PT_FLAG_* */
-    uint32_t pad[3];
+    uint32_t streams;        /* sample streams per pixel kept in flight at once (docs/SPEC.md §5): sample s goes to stream
+                                s mod streams, each stream has its own partial sum, the pixel is their fixed-order sum.
+                                0 = 1; at most 16. More streams = more rays per wavefront iteration, same picture definition. */
+    uint32_t pad[2];
 } pt_render_params; /* 64 B */
 
 typedef struct {

@@ -183,6 +183,31 @@ static inline void test_sphere(const pto_scene *s, uint32_t j, v3 o, v3 d, hit_t
     if (t < h->t || (t == h->t && id < h->id)) { h->t = t; h->id = id; h->is_sphere = 1; h->sph = j; }
 }
 
+/* SPEC §4.1: the child slots of node `i` for every blob layout, as float boxes + refs. Returns the slot count.
+ * layout 2 / 4: N slots of 32 B. layout 68 (BVH4Q): one 64-byte node
+ *   +0 origin f32[3] | +12 exponent u8[3],0 | +16 ref i32[4] | +32 qlo_x,qlo_y,qlo_z (u8[4] each) | +44 qhi_x,qhi_y,qhi_z
+ * with box = fma((float)q, 2^(e-127), origin) per axis. */
+static uint32_t node_children(uint32_t layout, const void *nodes, uint32_t i, slot_t out[4])
+{
+    if (layout == PTO_BVH_LAYOUT_4Q) {
+        const uint8_t *nd = (const uint8_t *)nodes + (size_t)i * 64;
+        float org[3], sc[3];
+        memcpy(org, nd, 12);
+        for (int k = 0; k < 3; ++k) sc[k] = bits2f((uint32_t)nd[12 + k] << 23);
+        for (int c = 0; c < 4; ++c) {
+            memcpy(&out[c].ref, nd + 16 + 4 * c, 4);
+            out[c].aux = 0;
+            for (int k = 0; k < 3; ++k) {
+                out[c].lo[k] = fma_((float)nd[32 + 4 * k + c], sc[k], org[k]);
+                out[c].hi[k] = fma_((float)nd[44 + 4 * k + c], sc[k], org[k]);
+            }
+        }
+        return 4;
+    }
+    memcpy(out, (const slot_t *)nodes + (size_t)i * layout, sizeof(slot_t) * layout);
+    return layout;
+}
+
 static void closest_hit(const pto_scene *s, v3 o, v3 d, hit_t *h, pto_stats *st)
 {
     h->t = INFINITY; h->id = PTO_MISS; h->is_sphere = 0; h->sph = 0;
@@ -198,8 +223,6 @@ static void closest_hit(const pto_scene *s, v3 o, v3 d, hit_t *h, pto_stats *st)
         inv[k] = 1.0f / dk;
         noi[k] = -(oo[k] * inv[k]);
     }
-    const uint32_t N = s->bvh_width;
-    const slot_t *nodes = (const slot_t *)s->nodes;
     const tri48_t *tris = (const tri48_t *)s->tris48;
     int32_t stack[512];
     int sp = 0;
@@ -207,7 +230,8 @@ static void closest_hit(const pto_scene *s, v3 o, v3 d, hit_t *h, pto_stats *st)
     while (sp > 0) {
         int32_t ref = stack[--sp];
         if (ref >= 0) {
-            const slot_t *nd = nodes + (size_t)ref * N;
+            slot_t nd[4];
+            const uint32_t N = node_children(s->bvh_width, s->nodes, (uint32_t)ref, nd);
             st->node_visits++;
             uint32_t keys[8]; int32_t refs[8]; int nh = 0;
             for (uint32_t c = 0; c < N; ++c) {
@@ -344,11 +368,18 @@ int pto_bsdf_sample(const pto_material *m, const float dv[3], const float nv[3],
     return 1;
 }
 
+#define PTO_MAX_STREAMS 16
+static uint32_t stream_count(const pto_params *p) { return p->streams ? p->streams : 1u; }
+
 static void trace_pixel(const pto_scene *s, const pto_params *p, uint32_t x, uint32_t y, float out[4], pto_stats *st)
 {
-    float acc[4] = { 0, 0, 0, 0 };
+    /* SPEC §5: K = streams partial sums per pixel; sample s accumulates into stream s mod K, in increasing s */
+    const uint32_t K = stream_count(p);
+    float accs[PTO_MAX_STREAMS][4];
+    memset(accs, 0, sizeof accs);
     uint32_t pixel = y * p->width + x;
     for (uint32_t si = 0; si < p->spp; ++si) {
+        float *acc = accs[si % K];
         uint32_t key = pto_path_key(p->seed, pixel, p->sample_offset + si);
         float of[3], df[3];
         pto_camera_ray(&s->cam, x, y, key, of, df);
@@ -400,7 +431,11 @@ static void trace_pixel(const pto_scene *s, const pto_params *p, uint32_t x, uin
         st->paths++;
     }
     float is = 1.0f / (float)p->spp;
-    for (int k = 0; k < 4; ++k) out[k] = acc[k] * is;
+    for (int k = 0; k < 4; ++k) {
+        float tot = accs[0][k];
+        for (uint32_t j = 1; j < K; ++j) tot = tot + accs[j][k]; /* ((s0 + s1) + s2) + ... */
+        out[k] = tot * is;
+    }
 }
 
 int pto_num_threads(void)
@@ -414,12 +449,12 @@ int pto_num_threads(void)
 
 int pto_render(const pto_scene *s, const pto_params *p, int threads, float *rgba, pto_stats *st)
 {
-    if (!s || !p || !rgba || p->spp == 0 || p->width == 0 || p->height == 0) return -1;
+    if (!s || !p || !rgba || p->spp == 0 || p->width == 0 || p->height == 0 || p->streams > PTO_MAX_STREAMS) return -1;
     if (s->n_spheres > 64) return -2;
     for (uint32_t i = 0; i < s->n_tris; ++i) if (s->tri_mat && s->tri_mat[i] >= s->n_mats) return -3;
     for (uint32_t i = 0; i < s->n_spheres; ++i) if (s->sph_mat && s->sph_mat[i] >= s->n_mats) return -3;
     if ((s->n_tris || s->n_spheres) && s->n_mats == 0) return -3;
-    if (s->nodes && s->bvh_width != 2 && s->bvh_width != 4) return -4;
+    if (s->nodes && s->bvh_width != 2 && s->bvh_width != 4 && s->bvh_width != PTO_BVH_LAYOUT_4Q) return -4;
     pto_stats tot; memset(&tot, 0, sizeof tot);
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
@@ -555,14 +590,14 @@ void pto_free(void *p) { free(p); }
 int pto_bvh_validate(uint32_t width, uint32_t n_nodes, const void *nodes_v, const void *tris_v,
                      uint32_t n_tris, const float *tri_verts, const uint32_t *tri_mat, uint32_t *max_depth_out)
 {
-    if (width != 2 && width != 4) return -1;
+    if (width != 2 && width != 4 && width != PTO_BVH_LAYOUT_4Q) return -1;
     if (n_tris == 0) return n_nodes == 0 ? 0 : -2;
     if (n_nodes == 0 || !nodes_v || !tris_v) return -2;
-    const slot_t *nodes = (const slot_t *)nodes_v;
+    const uint32_t W = (width == 2) ? 2u : 4u;
     const tri48_t *tris = (const tri48_t *)tris_v;
     uint8_t *seen = (uint8_t *)calloc(n_tris, 1), *nseen = (uint8_t *)calloc(n_nodes, 1);
     typedef struct { int32_t ref; box_t box; uint32_t depth; } ent;
-    ent *stk = (ent *)malloc(sizeof(ent) * (size_t)(n_nodes * (width - 1) + 8));
+    ent *stk = (ent *)malloc(sizeof(ent) * (size_t)(n_nodes * (W - 1) + 8));
     int rc = 0; uint32_t sp = 0, maxd = 0;
     ent root; root.ref = 0; root.depth = 1;
     for (int k = 0; k < 3; ++k) { root.box.lo[k] = -INFINITY; root.box.hi[k] = INFINITY; }
@@ -574,15 +609,16 @@ int pto_bvh_validate(uint32_t width, uint32_t n_nodes, const void *nodes_v, cons
         if (e.ref >= 0) {
             if ((uint32_t)e.ref >= n_nodes) { rc = -4; break; }
             if (nseen[e.ref]++) { rc = -5; break; } /* node reachable twice */
-            const slot_t *nd = nodes + (size_t)e.ref * width;
+            slot_t nd[4];
+            node_children(width, nodes_v, (uint32_t)e.ref, nd);
             int any = 0;
-            for (uint32_t c = 0; c < width; ++c) {
+            for (uint32_t c = 0; c < W; ++c) {
                 if (nd[c].ref == PTO_BVH_EMPTY) continue;
                 any = 1;
                 ent ch; ch.ref = nd[c].ref; ch.depth = e.depth + 1;
-                for (int k = 0; k < 3; ++k) {
-                    ch.box.lo[k] = nd[c].lo[k]; ch.box.hi[k] = nd[c].hi[k];
-                    if (!(nd[c].lo[k] >= e.box.lo[k] && nd[c].hi[k] <= e.box.hi[k])) rc = -6; /* child outside parent */
+                for (int k = 0; k < 3; ++k) { /* carry the intersection of all ancestor slot boxes down to the leaves */
+                    ch.box.lo[k] = max_(e.box.lo[k], nd[c].lo[k]); ch.box.hi[k] = min_(e.box.hi[k], nd[c].hi[k]);
+                    if (!(ch.box.lo[k] <= ch.box.hi[k])) rc = -6; /* a child box disjoint from an ancestor's */
                 }
                 stk[sp++] = ch;
             }

@@ -27,12 +27,15 @@ extern "C" {
 enum { PTO_LAMBERT = 0, PTO_METAL = 1, PTO_DIELECTRIC = 2 };
 #define PTO_MISS 0xFFFFFFFFu
 #define PTO_BVH_EMPTY 0x7fffffff
+#define PTO_BVH_LAYOUT_4Q 68u /* bvh_width value of the quantised 64-byte BVH4 node format (SPEC §4.1) */
 
 typedef struct { uint32_t kind; float albedo[3]; float emission[3]; float roughness; float ior; uint32_t pad[3]; } pto_material; /* 48 B */
 typedef struct { float origin[3], forward[3], right[3], up[3]; float scale, cx, cy; uint32_t jitter; } pto_camera;              /* 64 B */
 typedef struct {
     uint32_t width, height, spp, max_depth, rr_start, seed, sample_offset, mode;
-    float ray_eps; uint32_t rank, nranks, tile_size, flags, pad[3];
+    float ray_eps; uint32_t rank, nranks, tile_size, flags;
+    uint32_t streams; /* partial sums per pixel (SPEC §5); 0 = 1, at most 16 */
+    uint32_t pad[2];
 } pto_params; /* 64 B, same layout as pt_render_params */
 
 typedef struct {

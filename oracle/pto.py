@@ -27,7 +27,7 @@ class pto_params(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("max_depth", C.c_uint32),
                 ("rr_start", C.c_uint32), ("seed", C.c_uint32), ("sample_offset", C.c_uint32), ("mode", C.c_uint32),
                 ("ray_eps", C.c_float), ("rank", C.c_uint32), ("nranks", C.c_uint32), ("tile_size", C.c_uint32),
-                ("flags", C.c_uint32), ("pad", C.c_uint32 * 3)]
+                ("flags", C.c_uint32), ("streams", C.c_uint32), ("pad", C.c_uint32 * 2)]
 
 
 class pto_scene(C.Structure):
@@ -106,7 +106,7 @@ class Scene:
         self.keep["nodes"] = np.ascontiguousarray(nodes_bytes, np.uint8)
         self.keep["tris48"] = np.ascontiguousarray(tris_bytes, np.uint8)
         self.c.bvh_width = width
-        self.c.n_nodes = self.keep["nodes"].size // (32 * width)
+        self.c.n_nodes = self.keep["nodes"].size // (64 if width == 68 else 32 * width)
         self.c.nodes, self.c.tris48 = _p(self.keep["nodes"]), _p(self.keep["tris48"])
 
     def build_own_bvh(self):

@@ -33,7 +33,7 @@ PT_OK, PT_ERR_INVALID_ARGUMENT, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_OUT_OF_MEMO
     PT_ERR_UNSUPPORTED, PT_ERR_INTERNAL = range(8)
 PT_REFERENCE_SPHERE, PT_PATH_TRACE = 0, 1
 PT_LAMBERT, PT_METAL, PT_DIELECTRIC = 0, 1, 2
-PT_FLAG_PROFILE_KERNELS, PT_FLAG_COUNT_VISITS = 1, 2
+PT_FLAG_PROFILE_KERNELS, PT_FLAG_COUNT_VISITS, PT_FLAG_EXTEND_PACKED = 1, 2, 4
 PT_SCENE_CORNELL, PT_SCENE_CORNELL_GLASS, PT_SCENE_TRIANGLE_SOUP, PT_SCENE_CORNELL_TESS = 0, 1, 2, 3
 
 
@@ -55,7 +55,7 @@ class pt_render_params(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("max_depth", C.c_uint32),
                 ("rr_start", C.c_uint32), ("seed", C.c_uint32), ("sample_offset", C.c_uint32), ("mode", C.c_uint32),
                 ("ray_eps", C.c_float), ("rank", C.c_uint32), ("nranks", C.c_uint32), ("tile_size", C.c_uint32),
-                ("flags", C.c_uint32), ("pad", C.c_uint32 * 3)]
+                ("flags", C.c_uint32), ("streams", C.c_uint32), ("pad", C.c_uint32 * 2)]
 
 
 class pt_stats(C.Structure):

@@ -73,6 +73,10 @@ struct pt_scene {
     float sky[3] = { 0.f, 0.f, 0.f };
     bool have_cam = false, committed = false;
     BvhBlob bvh;
+    uint32_t layout = 0;                 // PT_BVH_WIDTH_* the scene was committed with
+    std::vector<uint8_t> packed_nodes;   // layout PT_BVH_WIDTH_4Q: the 64-byte nodes that are uploaded / read back
+    const void *node_data() const { return layout == PT_BVH_WIDTH_4Q ? (const void *)packed_nodes.data() : (const void *)bvh.slots.data(); }
+    uint64_t node_bytes() const { return layout == PT_BVH_WIDTH_4Q ? packed_nodes.size() : bvh.slots.size() * sizeof(BvhSlot); }
     DevBuf<float4> d_nodes, d_tris, d_tri_shade, d_spheres, d_mats;
     bool has_specular = false;
     DevBuf<uint32_t> d_sph_mat;
@@ -272,22 +276,26 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
 {
     if (!s) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "scene is NULL");
     pt_context *c = s->ctx;
-    if (bvh_width == PT_BVH_WIDTH_DEFAULT) bvh_width = PT_BVH_WIDTH_4;
-    if (bvh_width != 2 && bvh_width != 4) return fail(c, PT_ERR_INVALID_ARGUMENT, "bvh_width must be 0, 2 or 4");
+    if (bvh_width == PT_BVH_WIDTH_DEFAULT) bvh_width = PT_BVH_WIDTH_4Q;
+    if (bvh_width != PT_BVH_WIDTH_2 && bvh_width != PT_BVH_WIDTH_4 && bvh_width != PT_BVH_WIDTH_4Q)
+        return fail(c, PT_ERR_INVALID_ARGUMENT, "bvh_width must be one of PT_BVH_WIDTH_* (0, 2, 4, 68)");
     if (!s->have_cam) return fail(c, PT_ERR_INVALID_ARGUMENT, "no camera set");
     const uint32_t nt = (uint32_t)s->tri_mat.size(), ns = (uint32_t)s->sph_mat.size(), nm = (uint32_t)s->mats.size();
     if ((nt || ns) && nm == 0) return fail(c, PT_ERR_INVALID_ARGUMENT, "primitives but no materials");
     for (uint32_t i = 0; i < nt; ++i) if (s->tri_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "triangle %u: material id %u >= %u", i, s->tri_mat[i], nm);
     for (uint32_t i = 0; i < ns; ++i) if (s->sph_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "sphere %u: material id %u >= %u", i, s->sph_mat[i], nm);
 
-    build_bvh(s->verts.data(), s->tri_mat.data(), nt, bvh_width, s->bvh);
+    build_bvh(s->verts.data(), s->tri_mat.data(), nt, bvh_width == PT_BVH_WIDTH_2 ? 2u : 4u, s->bvh);
     if (s->bvh.max_depth > 90) return fail(c, PT_ERR_INTERNAL, "BVH depth %u exceeds the supported 90", s->bvh.max_depth);
+    s->layout = bvh_width;
+    s->packed_nodes.clear();
+    if (bvh_width == PT_BVH_WIDTH_4Q) quantize_bvh4(s->bvh, s->packed_nodes);
     if (!c) { s->committed = true; return PT_OK; } // detached scene: host-side blob only
 
     HIP_TRY(c, hipSetDevice(c->device));
     static_assert(sizeof(BvhSlot) == 32 && sizeof(BvhTri) == 48 && sizeof(pt_material) == 48, "blob layout");
-    HIP_TRY(c, s->d_nodes.ensure(s->bvh.slots.size() * 2));
-    HIP_TRY(c, s->d_tris.ensure(s->bvh.tris.size() * 3));
+    HIP_TRY(c, s->d_nodes.ensure((size_t)(s->node_bytes() / 16)));
+    HIP_TRY(c, s->d_tris.ensure(s->bvh.tris.size() * 3 + 1)); // +1 row: k_extend always fetches 4 rows, a triangle has 3
     HIP_TRY(c, s->d_tri_shade.ensure(s->bvh.tris.size()));
     {   // per-triangle shading record: ng = normalize(cross(e1,e2)) in exactly the op order of docs/SPEC.md §0 (fma, IEEE
         // sqrt and divide), so the bits equal what the kernel would compute from e1,e2; 16 B instead of two 16-B rows.
@@ -305,7 +313,7 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     HIP_TRY(c, s->d_spheres.ensure(ns));
     HIP_TRY(c, s->d_sph_mat.ensure(ns));
     HIP_TRY(c, s->d_mats.ensure((size_t)nm * 3));
-    if (!s->bvh.slots.empty()) HIP_TRY(c, hipMemcpy(s->d_nodes.p, s->bvh.slots.data(), s->bvh.slots.size() * sizeof(BvhSlot), hipMemcpyHostToDevice));
+    if (s->node_bytes()) HIP_TRY(c, hipMemcpy(s->d_nodes.p, s->node_data(), s->node_bytes(), hipMemcpyHostToDevice));
     if (!s->bvh.tris.empty()) HIP_TRY(c, hipMemcpy(s->d_tris.p, s->bvh.tris.data(), s->bvh.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
     if (ns) {
         HIP_TRY(c, hipMemcpy(s->d_spheres.p, s->spheres.data(), (size_t)ns * 16, hipMemcpyHostToDevice));
@@ -330,9 +338,9 @@ pt_status pt_scene_bvh_info(const pt_scene *s, pt_bvh_info *o)
     if (!s || !o) return fail(s ? s->ctx : nullptr, PT_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!s->committed) return fail(s->ctx, PT_ERR_NOT_COMMITTED, "scene not committed");
     std::memset(o, 0, sizeof *o);
-    o->width = s->bvh.width; o->n_nodes = s->bvh.n_nodes; o->n_tris = (uint32_t)s->bvh.tris.size();
+    o->width = s->layout; o->n_nodes = s->bvh.n_nodes; o->n_tris = (uint32_t)s->bvh.tris.size();
     o->max_depth = s->bvh.max_depth;
-    o->node_bytes = (uint64_t)s->bvh.slots.size() * sizeof(BvhSlot);
+    o->node_bytes = s->node_bytes();
     o->tri_bytes = (uint64_t)s->bvh.tris.size() * sizeof(BvhTri);
     o->build_ms = s->bvh.build_ms; o->sah_cost = s->bvh.sah_cost;
     o->reserved = s->bvh.stack_need;
@@ -343,9 +351,9 @@ pt_status pt_scene_bvh_read(const pt_scene *s, void *nodes, uint64_t node_bytes,
 {
     if (!s) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "scene is NULL");
     if (!s->committed) return fail(s->ctx, PT_ERR_NOT_COMMITTED, "scene not committed");
-    const uint64_t nb = (uint64_t)s->bvh.slots.size() * sizeof(BvhSlot), tb = (uint64_t)s->bvh.tris.size() * sizeof(BvhTri);
+    const uint64_t nb = s->node_bytes(), tb = (uint64_t)s->bvh.tris.size() * sizeof(BvhTri);
     if (node_bytes < nb || tri_bytes < tb || (nb && !nodes) || (tb && !tris48)) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "buffers too small: need %llu + %llu bytes", (unsigned long long)nb, (unsigned long long)tb);
-    if (nb) std::memcpy(nodes, s->bvh.slots.data(), nb);
+    if (nb) std::memcpy(nodes, s->node_data(), nb);
     if (tb) std::memcpy(tris48, s->bvh.tris.data(), tb);
     return PT_OK;
 }
@@ -378,6 +386,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     pt_stats out; std::memset(&out, 0, sizeof out);
     c->fb_valid = false;
     const bool profile = (p->flags & PT_FLAG_PROFILE_KERNELS) != 0, count = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
+    const uint32_t packed_chunk = (p->flags & PT_FLAG_EXTEND_PACKED) ? 128u : 0u;
 
     if (p->mode == PT_REFERENCE_SPHERE) {
         // Renderer.ComputeFrame: one dispatch, then the host blocks on the fence (Renderer.cs:1020,1036,972)
@@ -402,8 +411,11 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     if (p->max_depth == 0 || p->max_depth > 255) return fail(c, PT_ERR_INVALID_ARGUMENT, "max_depth must be in [1,255]");
     if (!std::isfinite(p->ray_eps) || p->ray_eps < 0.f) return fail(c, PT_ERR_INVALID_ARGUMENT, "ray_eps must be finite and >= 0");
 
+    if (p->streams > 16) return fail(c, PT_ERR_INVALID_ARGUMENT, "streams must be in [0,16]");
     const uint32_t nranks = p->nranks ? p->nranks : 1u;
-    const uint64_t slots64 = (uint64_t)lay.tiles_per_rank * kTilePixels;
+    const uint32_t streams = p->streams ? p->streams : 1u;
+    const uint32_t pixel_slots = lay.tiles_per_rank * kTilePixels;              // one slot per owned pixel ...
+    const uint64_t slots64 = (uint64_t)pixel_slots * streams;                   // ... per sample stream
     if (slots64 >= (1ull << 31)) return fail(c, PT_ERR_UNSUPPORTED, "frame too large");
     const uint32_t n_slots = (uint32_t)slots64;
 
@@ -428,6 +440,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     fp.width = p->width; fp.height = p->height; fp.spp = p->spp; fp.max_depth = p->max_depth; fp.rr_start = p->rr_start;
     fp.seed_hashed = host_pcg(p->seed); fp.sample_offset = p->sample_offset; fp.ray_eps = p->ray_eps;
     fp.rank = p->rank; fp.nranks = nranks; fp.tiles_x = lay.tiles_x; fp.n_tiles = lay.n_tiles;
+    fp.streams = streams; fp.slots_per_stream = pixel_slots;
 
     const DeviceScene &sc = s->ds;
     hipStream_t q = c->stream;
@@ -450,7 +463,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             if (!e0 || !e1 || !e2) return fail(c, PT_ERR_HIP, "hipEventCreate failed");
             HIP_TRY(c, hipEventRecord(e0, q));
         }
-        HIP_TRY(c, launch_extend(q, sc, ps, parity, bound, count));
+        HIP_TRY(c, launch_extend(q, sc, ps, parity, bound, count, packed_chunk));
         if (profile) HIP_TRY(c, hipEventRecord(e1, q));
         HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound, false));
         if (s->has_specular) HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound, true)); // metal + dielectric buckets
@@ -469,8 +482,9 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             if (bound == 0) done = true;
         }
     }
+    if (streams > 1) HIP_TRY(c, launch_reduce_streams(q, c->acc.p, pixel_slots, streams)); // plane 0 = the pixel sums = the gather payload
     if (nranks == 1)
-        HIP_TRY(c, launch_assemble(q, c->acc.p, 1, n_slots, p->width, p->height, lay.tiles_x, lay.n_tiles, 1.0f / (float)p->spp, c->fb.p, c->fb8.p));
+        HIP_TRY(c, launch_assemble(q, c->acc.p, 1, pixel_slots, p->width, p->height, lay.tiles_x, lay.n_tiles, 1.0f / (float)p->spp, c->fb.p, c->fb8.p));
     HIP_TRY(c, hipEventRecord(c->ev_stop, q));
     HIP_TRY(c, hipMemcpyAsync(c->h_counts + (size_t)kLag * kRingWords, c->counters.p, sizeof(uint32_t) * kCntTotalWords, hipMemcpyDeviceToHost, q));
     HIP_TRY(c, hipStreamSynchronize(q));
@@ -504,7 +518,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
         }
         out.other_ms = out.gpu_ms - out.extend_ms - out.shade_ms;
     }
-    c->n_slots = n_slots;
+    c->n_slots = pixel_slots;
     c->fb_valid = (nranks == 1);
     if (stats) *stats = out;
     return PT_OK;

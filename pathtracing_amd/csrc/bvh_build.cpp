@@ -210,4 +210,55 @@ void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint3
     out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// ---- BVH4Q: 64-byte nodes, child boxes quantised to 8 bits per coordinate on a per-node power-of-two grid
+// (docs/SPEC.md §4.1). decode(q) = fma((float)q, scale, origin) must enclose the float box it replaces; the
+// quantiser checks that with the very expression the traversal uses and nudges q outward when rounding bites.
+namespace {
+inline float scale_of(uint8_t e) { uint32_t b = (uint32_t)e << 23; float f; std::memcpy(&f, &b, 4); return f; }
+} // namespace
+
+void quantize_bvh4(const BvhBlob &in, std::vector<uint8_t> &out)
+{
+    out.assign((size_t)in.n_nodes * 64, 0);
+    for (uint32_t i = 0; i < in.n_nodes; ++i) {
+        const BvhSlot *s = &in.slots[(size_t)i * 4];
+        uint8_t *nd = &out[(size_t)i * 64];
+        float org[3]; uint8_t ex[3];
+        uint8_t qlo[3][4] = {}, qhi[3][4] = {};
+        for (int k = 0; k < 3; ++k) {
+            float lo = kInf, hi = -kInf;
+            for (int c = 0; c < 4; ++c) if (s[c].ref != kEmpty) { lo = std::min(lo, s[c].lo[k]); hi = std::max(hi, s[c].hi[k]); }
+            if (!(lo <= hi)) { lo = hi = 0.f; } // node without children (cannot happen for a built tree)
+            org[k] = lo;
+            int e = 1;
+            { // smallest power of two with 255*scale >= extent
+                const float ext = hi - lo;
+                int ee; const float m = std::frexp(ext / 255.0f, &ee); // ext/255 = m * 2^ee, m in [0.5,1)
+                e = (ext > 0.f) ? ee + 127 - (m == 0.5f ? 1 : 0) : 1;
+                e = std::min(std::max(e, 1), 254);
+            }
+            for (;;) { // quantise; widen the grid if a coordinate does not fit in 8 bits
+                const float sc = scale_of((uint8_t)e);
+                bool ok = true;
+                for (int c = 0; c < 4 && ok; ++c) {
+                    if (s[c].ref == kEmpty) continue;
+                    int ql = (int)std::floor((s[c].lo[k] - lo) / sc), qh = (int)std::ceil((s[c].hi[k] - lo) / sc);
+                    ql = std::min(std::max(ql, 0), 255); qh = std::min(std::max(qh, 0), 255);
+                    while (ql > 0 && !(std::fmaf((float)ql, sc, lo) <= s[c].lo[k])) --ql;
+                    while (qh < 255 && !(std::fmaf((float)qh, sc, lo) >= s[c].hi[k])) ++qh;
+                    if (!(std::fmaf((float)ql, sc, lo) <= s[c].lo[k]) || !(std::fmaf((float)qh, sc, lo) >= s[c].hi[k])) { ok = false; break; }
+                    qlo[k][c] = (uint8_t)ql; qhi[k][c] = (uint8_t)qh;
+                }
+                if (ok || e >= 254) break;
+                ++e;
+            }
+            ex[k] = (uint8_t)e;
+        }
+        std::memcpy(nd + 0, org, 12);
+        nd[12] = ex[0]; nd[13] = ex[1]; nd[14] = ex[2]; nd[15] = 0;
+        for (int c = 0; c < 4; ++c) std::memcpy(nd + 16 + 4 * c, &s[c].ref, 4);
+        for (int k = 0; k < 3; ++k) { std::memcpy(nd + 32 + 4 * k, qlo[k], 4); std::memcpy(nd + 44 + 4 * k, qhi[k], 4); }
+    }
+}
+
 } // namespace ptrt

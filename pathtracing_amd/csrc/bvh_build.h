@@ -21,4 +21,8 @@ struct BvhBlob {
 // verts9: 9 floats per triangle; mats may be null (all 0). width: 2 or 4.
 void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out);
 
+// BVH4Q (layout id 68): repack a width-4 blob into 64-byte nodes with 8-bit child boxes:
+//   +0 origin f32[3] | +12 exponent u8[3],0 | +16 ref i32[4] | +32 qlo_x,qlo_y,qlo_z u8[4] each | +44 qhi_x,qhi_y,qhi_z | +56 pad
+void quantize_bvh4(const BvhBlob &in, std::vector<uint8_t> &out);
+
 } // namespace ptrt

@@ -14,11 +14,9 @@
 // ever sees slots of its own shard, so a wavefront's push goes to exactly one per-shard counter.
 #include "ptrt_internal.h"
 #include "pt_device.h"
+#include <algorithm>
 #include <cstdlib>
 
-#ifndef PT_EXT_CHUNK_DEFAULT
-#define PT_EXT_CHUNK_DEFAULT 0
-#endif
 
 using namespace ptd;
 
@@ -40,8 +38,9 @@ PT_DEV void wave_push(uint32_t *counter, uint32_t *queue, bool pred, uint32_t va
     if (pred) queue[base + prefix] = value;
 }
 
-PT_DEV bool slot_pixel(uint32_t slot, const FrameParams &fp, uint32_t &x, uint32_t &y)
+PT_DEV bool slot_pixel(uint32_t slot_all, const FrameParams &fp, uint32_t &x, uint32_t &y)
 {
+    const uint32_t slot = slot_all % fp.slots_per_stream; // the K streams of a pixel share its pixel slot
     const uint32_t tl = slot >> (2 * kTileShift), inner = slot & (kTilePixels - 1);
     const uint32_t tile = fp.rank + fp.nranks * tl;
     if (tile >= fp.n_tiles) return false;
@@ -83,24 +82,82 @@ __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState p
     const uint32_t slot = (((j >> 8) * kShards + shard) << 8) | (j & 255u);
     uint32_t x = 0, y = 0;
     const bool in_range = j < ps.shard_cap && slot < ps.n_slots;
-    const bool valid = in_range && slot_pixel(slot, fp, x, y);
+    const uint32_t stream = slot / fp.slots_per_stream; // first sample of stream k is sample k
+    const bool valid = in_range && stream < fp.spp && slot_pixel(slot, fp, x, y);
     if (in_range) ps.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) {
-        const uint32_t key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset);
+        const uint32_t key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset + stream);
         V3 o, d;
         camera_ray_of(sc.cam, x, y, key, o, d);
         ps.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
         ps.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
         ps.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(key));
-        ps.sd[slot] = 0u;
+        ps.sd[slot] = stream << 8;
     }
     wave_push(&ps.counters[cnt_ext_index(0, shard)], ps.q_ext[0] + (size_t)shard * ps.shard_cap, valid, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int N, bool COUNT>
+// One inner-node visit for node layout L (PT_BVH_WIDTH_*): fetch the node, slab-test its children against the ray,
+// return (key, ref) sorted by ascending key = (bits(tn) & ~3) | slot; children that are missed/empty get key ~0.
+// L = 2 / 4 : N slots of {lo.xyz|ref, hi.xyz|0}  -> 2N 16-byte loads per lane
+// L = 4Q    : 64-byte node {origin|exps, refs, qlo x/y/z + qhi x, qhi y/z}, boxes decoded as fma(q, 2^e, origin)
+//             -> 4 loads per lane: half the bytes and half the (fully divergent) memory instructions per visit.
+// The first four 16-byte rows of the node arrive in r0..r3: the caller loads them (from the node OR, for a lane that
+// sits on a leaf, from its triangle) before it branches, so a wave-iteration has one memory round trip, not two.
+template <int L>
+PT_DEV constexpr int node_rows() { return L == PT_BVH_WIDTH_4 ? 8 : 4; }
+
+template <int L>
+PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, float4 r2, float4 r3, const RaySetup &rs, float t_best,
+                       uint32_t (&key)[4], int32_t (&ref)[4])
+{
+    constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
+    if (L == PT_BVH_WIDTH_4Q) {
+        const uint32_t eb = __float_as_uint(r0.w);
+        const float sx = __uint_as_float((eb & 0xffu) << 23), sy = __uint_as_float(((eb >> 8) & 0xffu) << 23),
+                    sz = __uint_as_float(((eb >> 16) & 0xffu) << 23);
+        const uint32_t qlx = __float_as_uint(r2.x), qly = __float_as_uint(r2.y), qlz = __float_as_uint(r2.z),
+                       qhx = __float_as_uint(r2.w), qhy = __float_as_uint(r3.x), qhz = __float_as_uint(r3.y);
+        ref[0] = __float_as_int(r1.x); ref[1] = __float_as_int(r1.y); ref[2] = __float_as_int(r1.z); ref[3] = __float_as_int(r1.w);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 lo = make_float4(fma_((float)((qlx >> (8 * c)) & 0xffu), sx, r0.x), fma_((float)((qly >> (8 * c)) & 0xffu), sy, r0.y),
+                                          fma_((float)((qlz >> (8 * c)) & 0xffu), sz, r0.z), 0.f);
+            const float4 hi = make_float4(fma_((float)((qhx >> (8 * c)) & 0xffu), sx, r0.x), fma_((float)((qhy >> (8 * c)) & 0xffu), sy, r0.y),
+                                          fma_((float)((qhz >> (8 * c)) & 0xffu), sz, r0.z), 0.f);
+            float tn;
+            const bool hb = box_test(lo, hi, rs, t_best, tn) && ref[c] != PT_BVH_EMPTY;
+            key[c] = hb ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+        }
+    } else {
+        float4 r[2 * N];
+        r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
+#pragma unroll
+        for (int i = 4; i < 2 * N; ++i) r[i] = nd[i]; // BVH4/128 B: second half of the node
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            float tn;
+            ref[c] = __float_as_int(r[2 * c].w);
+            const bool hb = box_test(r[2 * c], r[2 * c + 1], rs, t_best, tn) && ref[c] != PT_BVH_EMPTY;
+            key[c] = hb ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+        }
+    }
+    auto cswap = [&](int a, int b) {
+        if (key[a] > key[b]) {
+            const uint32_t tk = key[a]; key[a] = key[b]; key[b] = tk;
+            const int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
+        }
+    };
+    if (N == 2) { cswap(0, 1); }
+    else { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int L, bool COUNT>
 __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState ps, uint32_t parity)
 {
+    constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
     __shared__ int32_t s_stack[kStackLds * kExtBlock];
     const uint32_t shard = blockIdx.y;
     const uint32_t n = ps.counters[cnt_ext_index(parity, shard)];
@@ -151,42 +208,24 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
 
         while (cur != PT_BVH_EMPTY) {
             if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); break; }
-            if (cur >= 0) {
-                const float4 *nd = sc.nodes + (size_t)cur * (2 * N);
-                float4 r[2 * N];
-#pragma unroll
-                for (int i = 0; i < 2 * N; ++i) r[i] = nd[i];
+            // one fetch for both kinds of step: 4 rows from the node, or from the first triangle of the leaf
+            const bool inner = cur >= 0;
+            const uint32_t enc = (uint32_t)~cur, first = enc >> 3, more = enc & 7u; // leaf: `more` triangles after this one
+            const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 3;
+            const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
+            if (inner) {
+                uint32_t key[4];
+                int32_t ref[4];
+                visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref); // keys sorted ascending, misses = 0xFFFFFFFF at the end
                 if (COUNT) c_nodes++;
-                uint32_t key[N];
-                int32_t ref[N];
-#pragma unroll
-                for (int c = 0; c < N; ++c) {
-                    float tn;
-                    ref[c] = __float_as_int(r[2 * c].w);
-                    const bool hb = box_test(r[2 * c], r[2 * c + 1], rs, h.t, tn) && ref[c] != PT_BVH_EMPTY;
-                    key[c] = hb ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
-                }
-                auto cswap = [&](int a, int b) {
-                    if (key[a] > key[b]) {
-                        const uint32_t tk = key[a]; key[a] = key[b]; key[b] = tk;
-                        const int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
-                    }
-                };
-                if (N == 2) { cswap(0, 1); }
-                else { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); }
 #pragma unroll
                 for (int i = N - 1; i >= 1; --i)
                     if (key[i] != 0xFFFFFFFFu) push(ref[i]); // farthest first, nearest stays in `cur`
                 cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop();
             } else {
-                const uint32_t enc = (uint32_t)~cur, first = enc >> 3, cnt = (enc & 7u) + 1u;
-                for (uint32_t j = 0; j < cnt; ++j) {
-                    const uint32_t idx = first + j;
-                    const float4 *tp = sc.tris + (size_t)idx * 3;
-                    tri_test(tp[0], tp[1], tp[2], idx, o, d, h);
-                    if (COUNT) c_tris++;
-                }
-                cur = pop();
+                tri_test(r0, r1, r2, first, o, d, h);
+                if (COUNT) c_tris++;
+                cur = more ? (int32_t)~(((first + 1u) << 3) | (more - 1u)) : pop(); // rest of the leaf, in array order
             }
         }
 
@@ -211,9 +250,10 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
 #endif
 constexpr uint32_t kRefillIdle = PT_REFILL_IDLE;
 
-template <int N, bool COUNT>
+template <int L, bool COUNT>
 __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState ps, uint32_t parity, uint32_t chunk)
 {
+    constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
     __shared__ int32_t s_stack[kStackLds * 64];
     const uint32_t shard = blockIdx.y;
     const uint32_t n = ps.counters[cnt_ext_index(parity, shard)];
@@ -287,43 +327,24 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
         const uint32_t want = (next < end) ? kRefillIdle : 64u;
         for (;;) {
             if (cur != PT_BVH_EMPTY) {
+                const bool inner = cur >= 0;
+                const uint32_t enc = (uint32_t)~cur, first = enc >> 3, more = enc & 7u;
+                const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 3;
+                const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
                 if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; }
-                else if (cur >= 0) {
-                    const float4 *nd = sc.nodes + (size_t)cur * (2 * N);
-                    float4 r[2 * N];
-#pragma unroll
-                    for (int i = 0; i < 2 * N; ++i) r[i] = nd[i];
+                else if (inner) {
+                    uint32_t key[4];
+                    int32_t ref[4];
+                    visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref);
                     if (COUNT) c_nodes++;
-                    uint32_t key[N];
-                    int32_t ref[N];
-#pragma unroll
-                    for (int c = 0; c < N; ++c) {
-                        float tn;
-                        ref[c] = __float_as_int(r[2 * c].w);
-                        const bool hb = box_test(r[2 * c], r[2 * c + 1], rs, h.t, tn) && ref[c] != PT_BVH_EMPTY;
-                        key[c] = hb ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
-                    }
-                    auto cswap = [&](int a, int b) {
-                        if (key[a] > key[b]) {
-                            const uint32_t tk = key[a]; key[a] = key[b]; key[b] = tk;
-                            const int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
-                        }
-                    };
-                    if (N == 2) { cswap(0, 1); }
-                    else { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); }
 #pragma unroll
                     for (int i = N - 1; i >= 1; --i)
                         if (key[i] != 0xFFFFFFFFu) push(ref[i]);
                     cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop();
                 } else {
-                    const uint32_t enc = (uint32_t)~cur, first = enc >> 3, cnt = (enc & 7u) + 1u;
-                    for (uint32_t j = 0; j < cnt; ++j) {
-                        const uint32_t idx = first + j;
-                        const float4 *tp = sc.tris + (size_t)idx * 3;
-                        tri_test(tp[0], tp[1], tp[2], idx, o, d, h);
-                        if (COUNT) c_tris++;
-                    }
-                    cur = pop();
+                    tri_test(r0, r1, r2, first, o, d, h);
+                    if (COUNT) c_tris++;
+                    cur = more ? (int32_t)~(((first + 1u) << 3) | (more - 1u)) : pop();
                 }
             }
             const uint32_t busy = (uint32_t)__popcll(__ballot(has && cur != PT_BVH_EMPTY));
@@ -347,25 +368,24 @@ template <bool SPEC>
 __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, FrameParams fp, uint32_t parity)
 {
     const uint32_t shard = blockIdx.y;
-    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
     const size_t qbase = (size_t)shard * ps.shard_cap;
-    uint32_t total, b = B_LAMBERT, slot = 0u;
-    bool active;
+    uint32_t total, c0 = 0u;
     if (SPEC) {
-        const uint32_t c0 = ps.counters[cnt_bucket_index(parity, B_METAL, shard)];
+        c0 = ps.counters[cnt_bucket_index(parity, B_METAL, shard)];
         total = c0 + ps.counters[cnt_bucket_index(parity, B_DIELECTRIC, shard)];
-        if (gid < 2u) // the other parity's buckets were consumed by the previous k_shade<true>; k_shade<false>(i+1) fills them
-            ps.counters[cnt_bucket_index(parity ^ 1u, B_METAL + gid, shard)] = 0u;
-        if (blockIdx.x * kBlock >= total) return;
-        active = gid < total;
+        if (blockIdx.x == 0 && threadIdx.x < 2u) // the other parity's buckets were consumed by the previous k_shade<true>
+            ps.counters[cnt_bucket_index(parity ^ 1u, B_METAL + threadIdx.x, shard)] = 0u;
+    } else total = ps.counters[cnt_ext_index(parity, shard)];
+    // SPEC: a small fixed grid strides over the (usually short, unknown-length) specular buckets, so an empty bucket
+    // costs a few hundred trivial blocks instead of one per 256 queue slots. !SPEC: exactly one pass, grid sized by the host.
+    for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
+    const uint32_t gid = base + threadIdx.x;
+    const bool active = gid < total;
+    uint32_t b = B_LAMBERT, slot = 0u;
+    if (SPEC) {
         b = gid >= c0 ? B_DIELECTRIC : B_METAL;
         if (active) slot = ps.q_bucket[b][qbase + (gid >= c0 ? gid - c0 : gid)];
-    } else {
-        total = ps.counters[cnt_ext_index(parity, shard)];
-        if (blockIdx.x * kBlock >= total) return;
-        active = gid < total;
-        if (active) slot = ps.q_ext[parity][qbase + gid];
-    }
+    } else if (active) slot = ps.q_ext[parity][qbase + gid];
     bool alive = false;
     uint32_t defer = 0u; // SPEC == false: bucket this lane's hit must be shaded in (0 = handled here)
 
@@ -439,8 +459,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
         } else if (term) {
             if (!touched) { A = ps.acc[slot]; touched = true; }
             A.w += 1.0f;
-            ++sample;
-            if (sample < fp.spp) { // regenerate the next sample of this pixel in place
+            sample += fp.streams;
+            if (sample < fp.spp) { // regenerate this stream's next sample of the pixel in place
                 uint32_t x = 0, y = 0;
                 slot_pixel(slot, fp, x, y);
                 key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset + sample);
@@ -464,6 +484,22 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
         wave_push(&ps.counters[cnt_bucket_index(parity, B_METAL, shard)], ps.q_bucket[B_METAL] + qbase, defer == B_METAL, slot);
         wave_push(&ps.counters[cnt_bucket_index(parity, B_DIELECTRIC, shard)], ps.q_bucket[B_DIELECTRIC] + qbase, defer == B_DIELECTRIC, slot);
     }
+    if (!SPEC) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sum of a pixel's K stream partials in the fixed order ((s0 + s1) + s2) + ... (docs/SPEC.md §5), into plane 0.
+__global__ void __launch_bounds__(kBlock) k_reduce_streams(float4 *__restrict__ acc, uint32_t slots_per_stream, uint32_t streams)
+{
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= slots_per_stream) return;
+    float4 t = acc[slot];
+    for (uint32_t k = 1; k < streams; ++k) {
+        const float4 a = acc[(size_t)k * slots_per_stream + slot];
+        t.x = t.x + a.x; t.y = t.y + a.y; t.z = t.z + a.z; t.w = t.w + a.w;
+    }
+    acc[slot] = t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -503,41 +539,46 @@ hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState
     return hipGetLastError();
 }
 
-hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count)
+hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count,
+                         uint32_t packed_chunk)
 {
-    // Rays per wavefront of the packed kernel; 0 selects the one-ray-per-lane kernel. PTRT_EXT_CHUNK overrides (A/B aid).
-    static const uint32_t chunk_cfg = [] {
-        const char *e = getenv("PTRT_EXT_CHUNK");
-        return e ? (uint32_t)strtoul(e, nullptr, 10) : (uint32_t)PT_EXT_CHUNK_DEFAULT;
-    }();
-    if (chunk_cfg >= 64u) {
-        const uint32_t chunk = chunk_cfg;
+    // packed_chunk >= 64: rays per wavefront of the lane-packing kernel (PT_FLAG_EXTEND_PACKED); 0: one ray per lane.
+    // Measured on MI355X: packing raises lane utilisation but is slower at every chunk size, because the
+    // kernel is bound by outstanding divergent node fetches and fewer waves means fewer of them; it stays selectable.
+#define PT_LAUNCH_BY_LAYOUT(KERNEL, GRID, BLOCK, ...)                                                                    \
+    switch (sc.bvh_width) {                                                                                              \
+    case PT_BVH_WIDTH_2:  if (count) hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_2, true>), GRID, BLOCK, 0, s, __VA_ARGS__);  \
+                          else hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_2, false>), GRID, BLOCK, 0, s, __VA_ARGS__); break; \
+    case PT_BVH_WIDTH_4:  if (count) hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_4, true>), GRID, BLOCK, 0, s, __VA_ARGS__);  \
+                          else hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_4, false>), GRID, BLOCK, 0, s, __VA_ARGS__); break; \
+    case PT_BVH_WIDTH_4Q: if (count) hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_4Q, true>), GRID, BLOCK, 0, s, __VA_ARGS__); \
+                          else hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_4Q, false>), GRID, BLOCK, 0, s, __VA_ARGS__); break; \
+    default: return hipErrorInvalidValue;                                                                                \
+    }
+    if (packed_chunk >= 64u) {
+        const uint32_t chunk = packed_chunk;
         const dim3 pgrid(shard_bound ? (shard_bound + chunk - 1) / chunk : 1u, kShards), pblock(64);
-        if (sc.bvh_width == 4) {
-            if (count) hipLaunchKernelGGL((k_extend_packed<4, true>), pgrid, pblock, 0, s, sc, ps, parity, chunk);
-            else hipLaunchKernelGGL((k_extend_packed<4, false>), pgrid, pblock, 0, s, sc, ps, parity, chunk);
-        } else {
-            if (count) hipLaunchKernelGGL((k_extend_packed<2, true>), pgrid, pblock, 0, s, sc, ps, parity, chunk);
-            else hipLaunchKernelGGL((k_extend_packed<2, false>), pgrid, pblock, 0, s, sc, ps, parity, chunk);
-        }
+        PT_LAUNCH_BY_LAYOUT(k_extend_packed, pgrid, pblock, sc, ps, parity, chunk)
         return hipGetLastError();
     }
     const dim3 grid(shard_bound ? (shard_bound + kExtBlock - 1) / kExtBlock : 1u, kShards), block(kExtBlock);
-    if (sc.bvh_width == 4) {
-        if (count) hipLaunchKernelGGL((k_extend<4, true>), grid, block, 0, s, sc, ps, parity);
-        else hipLaunchKernelGGL((k_extend<4, false>), grid, block, 0, s, sc, ps, parity);
-    } else {
-        if (count) hipLaunchKernelGGL((k_extend<2, true>), grid, block, 0, s, sc, ps, parity);
-        else hipLaunchKernelGGL((k_extend<2, false>), grid, block, 0, s, sc, ps, parity);
-    }
+    PT_LAUNCH_BY_LAYOUT(k_extend, grid, block, sc, ps, parity)
+#undef PT_LAUNCH_BY_LAYOUT
     return hipGetLastError();
 }
 
 hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, bool specular)
 {
     const dim3 grid(blocks_for(shard_bound), kShards), block(kBlock);
-    if (specular) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, sc, ps, fp, parity);
+    const dim3 sgrid(std::min(blocks_for(shard_bound), 16u), kShards); // grid-stride over the specular buckets
+    if (specular) hipLaunchKernelGGL(k_shade<true>, sgrid, block, 0, s, sc, ps, fp, parity);
     else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, sc, ps, fp, parity);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_streams(hipStream_t s, float4 *acc, uint32_t slots_per_stream, uint32_t streams)
+{
+    hipLaunchKernelGGL(k_reduce_streams, dim3(blocks_for(slots_per_stream)), dim3(kBlock), 0, s, acc, slots_per_stream, streams);
     return hipGetLastError();
 }
 

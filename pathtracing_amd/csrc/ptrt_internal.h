@@ -79,14 +79,17 @@ struct FrameParams {
     uint32_t width, height, spp, max_depth, rr_start, seed_hashed, sample_offset;
     float ray_eps;
     uint32_t rank, nranks, tiles_x, n_tiles;
+    uint32_t streams;          // K sample streams per pixel (docs/SPEC.md §5); slot = stream * slots_per_stream + pixel slot
+    uint32_t slots_per_stream; // pixel slots of this rank (tiles_per_rank * 4096)
 };
 
 // kernel launchers (kernels.hip). All enqueue on `s` and return the launch error.
 // `shard_bound` = upper bound of any shard's queue length for this launch.
 hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4 *out_f, uint32_t *out_rgba8);
 hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp);
-hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count);
+hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count, uint32_t packed_chunk);
 hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, bool specular);
+hipError_t launch_reduce_streams(hipStream_t s, float4 *acc, uint32_t slots_per_stream, uint32_t streams);
 hipError_t launch_assemble(hipStream_t s, const float4 *gathered, uint32_t nranks, uint32_t slots_per_rank,
                            uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, float inv_spp,
                            float4 *fb, uint32_t *fb8);

@@ -91,10 +91,11 @@ def build_bvh_detached(scene, bvh_width=0):
 
 
 def make_params(width, height, spp=1, max_depth=8, rr_start=3, seed=0x5EED0001, mode=N.PT_PATH_TRACE, ray_eps=1e-4,
-                rank=0, nranks=1, flags=0, sample_offset=0):
+                rank=0, nranks=1, flags=0, sample_offset=0, streams=1):
     p = N.pt_render_params()
     p.width, p.height, p.spp, p.max_depth, p.rr_start, p.seed = width, height, spp, max_depth, rr_start, seed
     p.sample_offset, p.mode, p.ray_eps, p.rank, p.nranks, p.tile_size, p.flags = sample_offset, mode, ray_eps, rank, nranks, 0, flags
+    p.streams = streams
     return p
 
 

@@ -62,7 +62,7 @@ def test_reference_sphere_ragged_sizes(P, pto, renderer, w, h):
     assert np.array_equal(renderer.ReadFramebuffer(), of) and np.array_equal(renderer.ReadFramebufferRGBA8(), ob)
 
 
-@pytest.mark.parametrize("width", [2, 4])
+@pytest.mark.parametrize("width", [2, 4, 68])
 def test_c1_cornell(P, pto, renderer, width):
     """BASELINE config C1: Cornell box, 4 Lambert spheres + area light, 256x256, 4 spp."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL, 0, 0x5EED0001, 256, 256)
@@ -71,19 +71,31 @@ def test_c1_cornell(P, pto, renderer, width):
     assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests)
 
 
-@pytest.mark.parametrize("width", [2, 4])
+@pytest.mark.parametrize("width", [2, 4, 68])
 def test_c4_glass_metal_depth16(P, pto, renderer, width):
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, 200, 150)
     img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(200, 150, spp=8, max_depth=16), width)
     assert_parity(img, st, ref, ost)
 
 
-@pytest.mark.parametrize("width", [2, 4])
+@pytest.mark.parametrize("width", [2, 4, 68])
 def test_c3_triangle_soup(P, pto, renderer, width):
     sd = P.make_scene(P.native.PT_SCENE_TRIANGLE_SOUP, 50000, 0x5EED0001, 160, 120)
     img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(160, 120, spp=4, max_depth=8), width, count=True)
     assert_parity(img, st, ref, ost)
     assert (st.node_visits, st.tri_tests) == (ost.node_visits, ost.tri_tests)
+
+
+def test_packed_extend_kernel_is_identical(P, pto, renderer):
+    """PT_FLAG_EXTEND_PACKED (ballot/mbcnt lane refill) must not change a single bit nor a single visit count."""
+    sd = P.make_scene(P.native.PT_SCENE_TRIANGLE_SOUP, 30000, 3, 200, 150)
+    p = P.make_params(200, 150, spp=5, max_depth=8, flags=P.native.PT_FLAG_EXTEND_PACKED)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, p, 4, count=True)
+    assert_parity(img, st, ref, ost)
+    assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests)
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 3, 130, 70)
+    p = P.make_params(130, 70, spp=3, max_depth=12, flags=P.native.PT_FLAG_EXTEND_PACKED)
+    assert_parity(*run_both(P, pto, renderer, sd, p, 2))
 
 
 def test_c5_tessellated_cornell(P, pto, renderer):
@@ -139,6 +151,28 @@ def test_rank_partition_is_image_invariant(P, pto, renderer):
         assert np.array_equal(renderer.ReadFramebuffer(), want), nranks
 
 
+@pytest.mark.parametrize("streams", [2, 4, 7])
+def test_sample_streams(P, pto, renderer, streams):
+    """SPEC §5: K sample streams per pixel in flight, each with its own partial sum, summed in fixed order.
+    The oracle forms the same partial sums, so the picture stays bit-identical for every K (also K > spp, K not dividing spp)."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 5, 150, 100)
+    for spp in (1, 5, 8):
+        img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(150, 100, spp=spp, max_depth=10, streams=streams), 68)
+        assert_parity(img, st, ref, ost)
+    # and the tile partition still does not change the picture
+    import torch
+    renderer.Params = P.make_params(150, 100, spp=6, max_depth=6, streams=streams)
+    one = renderer.Render(0.0); want = renderer.ReadFramebuffer()
+    blocks = []
+    for rank in range(2):
+        renderer.Params = P.make_params(150, 100, spp=6, max_depth=6, streams=streams, rank=rank, nranks=2)
+        renderer.Render(0.0)
+        blocks.append(torch.as_tensor(renderer.TilesDevice(), device="cuda").clone())
+    g = torch.cat(blocks); torch.cuda.synchronize()
+    renderer.AssembleTiles(g.data_ptr(), g.numel())
+    assert np.array_equal(renderer.ReadFramebuffer(), want)
+
+
 def test_edge_cases(P, pto, renderer):
     N = P.native
     cam = P.make_scene(0, 0, 0, 70, 40).cam
@@ -151,7 +185,7 @@ def test_edge_cases(P, pto, renderer):
     sd = P.SceneData(cam=cam)
     sd.verts = np.array([[-1, -1, 0, 1, -1, 0, 0, 1, 0]], np.float32); sd.tri_mat = np.zeros(1, np.uint32)
     m = np.zeros(1, P.MATERIAL_DTYPE); m["albedo"] = 0.5; m["emission"] = (1, 2, 3); sd.mats = m
-    for width in (2, 4):
+    for width in (2, 4, 68):
         img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(70, 40, spp=1, max_depth=1), width)
         assert_parity(img, st, ref, ost)
         assert st.rays == 70 * 40 and img[..., 0].max() == 1.0

@@ -10,18 +10,19 @@ which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["cornell", "glass", "s
 widths = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2, 4]
 cfg = {"cornell": (N.PT_SCENE_CORNELL, 0, 8), "glass": (N.PT_SCENE_CORNELL_GLASS, 0, 16),
        "soup": (N.PT_SCENE_TRIANGLE_SOUP, 1 << 20, 8), "tess": (N.PT_SCENE_CORNELL_TESS, 1 << 20, 8)}
+XF = int(os.environ.get('PT_XFLAGS', '0')); ST = int(os.environ.get('PT_STREAMS', '1'))
 r = P.Renderer(P.Window(W, H)); r.Init()
 for name in which:
     kind, detail, depth = cfg[name]
     sd = P.make_scene(kind, detail, 0x5EED0001, W, H)
     for width in widths:
         r.SetScene(sd, width)
-        r.Params = P.make_params(W, H, spp=spp, max_depth=depth)
+        r.Params = P.make_params(W, H, spp=spp, max_depth=depth, flags=XF, streams=ST)
         r.Render(0.0)
         best = min((r.Render(0.0) for _ in range(2)), key=lambda s: s.gpu_ms)
-        r.Params = P.make_params(W, H, spp=spp, max_depth=depth, flags=N.PT_FLAG_PROFILE_KERNELS)
+        r.Params = P.make_params(W, H, spp=spp, max_depth=depth, flags=N.PT_FLAG_PROFILE_KERNELS | XF, streams=ST)
         pr = r.Render(0.0)
-        r.Params = P.make_params(W, H, spp=min(spp, 2), max_depth=depth, flags=N.PT_FLAG_COUNT_VISITS)
+        r.Params = P.make_params(W, H, spp=min(spp, 2), max_depth=depth, flags=N.PT_FLAG_COUNT_VISITS | XF, streams=ST)
         c = r.Render(0.0)
         info = r.BvhInfo()
         print(f"{name:8s} bvh{width} rays {best.rays/1e6:8.1f}M  {best.gpu_ms:8.2f} ms  {best.rays/best.gpu_ms/1e3:8.1f} Mrays/s  "
