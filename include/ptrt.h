@@ -56,7 +56,8 @@ enum { PT_LAMBERT = 0, PT_METAL = 1, PT_DIELECTRIC = 2 };
 enum {
     PT_FLAG_PROFILE_KERNELS = 1u, /* bracket every kernel with HIP events on the context's stream; fills pt_stats.*_ms */
     PT_FLAG_COUNT_VISITS = 2u,    /* count BVH node visits / triangle / sphere tests on the device (slower build of extend) */
-    PT_FLAG_EXTEND_PACKED = 4u    /* lane-packing extend kernel: a wavefront owns 128 queue entries and refills idle lanes by ballot */
+    PT_FLAG_EXTEND_PACKED = 4u,   /* force the lane-packing extend kernel (a wavefront owns a chunk of the queue and refills idle lanes by ballot) */
+    PT_FLAG_EXTEND_SIMPLE = 8u    /* force the one-ray-per-lane extend kernel. Neither flag: probed per scene (pt_stats.reserved[0]) */
 };
 /* pt_scene_commit options */
 enum {

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -58,6 +59,7 @@ struct pt_context {
     uint32_t *h_counts = nullptr; // pinned: kLag readbacks of the per-shard queue sizes + one copy of all counters
     hipEvent_t ev_lag[kLag] = {};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_probe[4] = {}; // brackets of the two probe iterations that pick the extend kernel
     std::vector<hipEvent_t> ev_pool;
     uint32_t fb_w = 0, fb_h = 0;
     uint32_t n_slots = 0; // slots of the last path-traced frame (acc layout)
@@ -79,6 +81,7 @@ struct pt_scene {
     uint64_t node_bytes() const { return layout == PT_BVH_WIDTH_4Q ? packed_nodes.size() : bvh.slots.size() * sizeof(BvhSlot); }
     DevBuf<float4> d_nodes, d_tris, d_tri_shade, d_spheres, d_mats;
     bool has_specular = false;
+    uint32_t ext_choice = 0;             // extend kernel picked by the probe of an earlier frame (0 = none yet, 1 = simple, 2 = packed)
     DevBuf<uint32_t> d_sph_mat;
     DeviceScene ds{};
 };
@@ -165,6 +168,7 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
     bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * ((size_t)kLag * kRingWords + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess;
     for (uint32_t i = 0; ok && i < kLag; ++i) ok = hipEventCreateWithFlags(&c->ev_lag[i], hipEventDisableTiming) == hipSuccess;
+    for (uint32_t i = 0; ok && i < 4; ++i) ok = hipEventCreate(&c->ev_probe[i]) == hipSuccess;
     ok = ok && c->counters.ensure(kCntTotalWords) == hipSuccess;
     if (!ok) { pt_context_destroy(c); return fail(nullptr, PT_ERR_HIP, "context resource creation failed"); }
     *out = c;
@@ -181,6 +185,7 @@ void pt_context_destroy(pt_context *c)
     for (auto &q : c->q_b) q.release();
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     for (auto &e : c->ev_lag) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_probe) if (e) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -327,6 +332,7 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     for (int k = 0; k < 3; ++k) d.sky[k] = s->sky[k];
     d.bvh_width = bvh_width;
     d.cam = s->cam;
+    s->ext_choice = 0;
     s->has_specular = false;
     for (const pt_material &m : s->mats) if (m.kind != PT_LAMBERT) s->has_specular = true;
     s->committed = true;
@@ -386,7 +392,10 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     pt_stats out; std::memset(&out, 0, sizeof out);
     c->fb_valid = false;
     const bool profile = (p->flags & PT_FLAG_PROFILE_KERNELS) != 0, count = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
-    const uint32_t packed_chunk = (p->flags & PT_FLAG_EXTEND_PACKED) ? 128u : 0u;
+    static const uint32_t chunk_env = [] { const char *e = getenv("PTRT_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }(); // tuning aid
+    // rays per wavefront of the lane-packing kernel: 256 once several sample streams keep the queues long, else 128 (measured)
+    const uint32_t packed_chunk = chunk_env >= 64u ? chunk_env : ((p->streams >= 4u) ? 256u : 128u);
+    const uint32_t forced_choice = (p->flags & PT_FLAG_EXTEND_PACKED) ? 2u : (p->flags & PT_FLAG_EXTEND_SIMPLE) ? 1u : 0u;
 
     if (p->mode == PT_REFERENCE_SPHERE) {
         // Renderer.ComputeFrame: one dispatch, then the host blocks on the fence (Renderer.cs:1020,1036,972)
@@ -454,6 +463,13 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     const uint64_t max_iters = (uint64_t)p->spp * p->max_depth + kLag + 2;
     size_t nev = 0;
     bool done = false;
+    // Which extend kernel: forced by a flag, remembered from an earlier frame of this scene, or probed now — iteration 2
+    // runs the one-ray-per-lane kernel, iteration 3 the lane-packing one (bit-identical results), each bracketed by
+    // events; the faster per ray wins for the rest of the frame and for later frames. Deep incoherent traversals
+    // (1M-triangle soup) gain ~1.5x from packing, shallow ones (walls of a box) lose ~8 %, and nothing static tells them apart.
+    pt_scene *scene_mut = const_cast<pt_scene *>(s);
+    uint32_t ext_choice = forced_choice ? forced_choice : scene_mut->ext_choice; // 0 = still probing, 1 = simple, 2 = packed
+    uint64_t probe_n[2] = { 0, 0 };
     while (!done) {
         if (iters >= max_iters) return fail(c, PT_ERR_INTERNAL, "wavefront loop did not drain after %u iterations", iters);
         const uint32_t parity = iters & 1u;
@@ -463,7 +479,11 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             if (!e0 || !e1 || !e2) return fail(c, PT_ERR_HIP, "hipEventCreate failed");
             HIP_TRY(c, hipEventRecord(e0, q));
         }
-        HIP_TRY(c, launch_extend(q, sc, ps, parity, bound, count, packed_chunk));
+        const bool probing = ext_choice == 0u && (iters == 2u || iters == 3u);
+        const bool use_packed = ext_choice == 2u || (probing && iters == 3u);
+        if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(iters - 2u) * 2u], q));
+        HIP_TRY(c, launch_extend(q, sc, ps, parity, bound, count, use_packed ? packed_chunk : 0u));
+        if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(iters - 2u) * 2u + 1u], q));
         if (profile) HIP_TRY(c, hipEventRecord(e1, q));
         HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound, false));
         if (s->has_specular) HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound, true)); // metal + dielectric buckets
@@ -477,9 +497,23 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             const uint32_t old = (iters - kLag) % kLag; // iteration iters-kLag: its survivors bound every later queue
             HIP_TRY(c, hipEventSynchronize(c->ev_lag[old]));
             uint32_t mx = 0; // a shard's queue only shrinks (its slots die, none are born): its old size bounds all later ones
-            for (uint32_t sh = 0; sh < kShards; ++sh) mx = std::max(mx, c->h_counts[(size_t)old * kRingWords + sh * kCounterStride]);
+            uint64_t total = 0;
+            for (uint32_t sh = 0; sh < kShards; ++sh) {
+                const uint32_t n = c->h_counts[(size_t)old * kRingWords + sh * kCounterStride];
+                mx = std::max(mx, n); total += n;
+            }
             bound = mx;
             if (bound == 0) done = true;
+            const uint32_t old_iter = iters - kLag; // `total` = rays of iteration old_iter + 1
+            if (ext_choice == 0u && (old_iter == 1u || old_iter == 2u)) probe_n[old_iter - 1u] = total;
+            if (ext_choice == 0u && old_iter == 3u) { // iterations 2 and 3 (and their events) are complete by now
+                float ms_simple = 0.f, ms_packed = 0.f;
+                HIP_TRY(c, hipEventElapsedTime(&ms_simple, c->ev_probe[0], c->ev_probe[1]));
+                HIP_TRY(c, hipEventElapsedTime(&ms_packed, c->ev_probe[2], c->ev_probe[3]));
+                const double r_simple = probe_n[0] / std::max((double)ms_simple, 1e-6), r_packed = probe_n[1] / std::max((double)ms_packed, 1e-6);
+                ext_choice = (probe_n[0] && probe_n[1] && r_packed > 1.10 * r_simple) ? 2u : 1u;
+                scene_mut->ext_choice = ext_choice;
+            }
         }
     }
     if (streams > 1) HIP_TRY(c, launch_reduce_streams(q, c->acc.p, pixel_slots, streams)); // plane 0 = the pixel sums = the gather payload
@@ -500,6 +534,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     out.gpu_ms = ms;
     out.node_visits = u64_at(kCntNodes); out.tri_tests = u64_at(kCntTris); out.sphere_tests = u64_at(kCntSph);
     out.iterations = iters; out.extend_launches = iters;
+    out.reserved[0] = ext_choice; // extend kernel in use at frame end: 1 = one ray per lane, 2 = lane-packing, 0 = frame too short to probe
     {   // paths = owned in-image pixels x spp
         uint64_t px = 0;
         for (uint32_t t = p->rank; t < lay.n_tiles; t += nranks) {
