@@ -10,9 +10,11 @@ scene, and the only data-path collective is ONE gather of per-rank tile radiance
 Total work per frame is fixed => "scaling": "strong". value = rays traced by all ranks / wall time (max over ranks).
 
 Extra objects on the JSON line (task §④):
-  roofline     : dominant kernel = k_extend (BVH traversal + intersection). achieved = algorithmic bytes per launch
-                 (B_ray x rays per launch, DESIGN.md "Roofline") / mean launch duration, measured live with HIP events
-                 on the library's own stream (pt_stats.extend_ms, PT_FLAG_PROFILE_KERNELS) in a separate, untimed frame.
+  roofline     : dominant kernel = the extend kernel (BVH traversal + intersection). achieved = algorithmic bytes per
+                 launch (B_ray x rays per launch) / mean launch duration, measured live with HIP events on
+                 the library's own stream (pt_stats.extend_ms, PT_FLAG_PROFILE_KERNELS) in a separate, untimed frame.
+                 traffic = rocprofv3 FETCH_SIZE(x2, gfx950)+WRITE_SIZE per launch from the committed PMC passes
+                 (profiles/pmc_latest.json) when they were taken on this very workload, else null.
   cpu_baseline : the scalar C oracle ("port"; the reference has no CPU path and cannot be built here) timed on this
                  host's cores over a bounded sample of the same workload (same scene, same BVH bytes, 1080p, low spp).
 """
@@ -32,18 +34,21 @@ HBM_ACHIEVABLE_GBS = 6290.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="cornell_tess", choices=["cornell_tess", "cornell", "cornell_glass", "soup"])
     ap.add_argument("--tris", type=int, default=1 << 20)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--max-depth", type=int, default=8)
-    ap.add_argument("--bvh-width", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=8, help="sample streams per pixel in flight (docs/SPEC.md §5)")
+    ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default (68 = BVH4Q)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N>1 ranks on ONE GPU over gloo (CPU-staged gather): rehearsal of the N>1 code path, not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -59,21 +64,29 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libptrt has no CPU path")
-    torch.cuda.set_device(local_rank)
+    device = 0 if args.rehearse_gloo else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))  # nccl == RCCL on ROCm
 
     kinds = {"cornell_tess": N.PT_SCENE_CORNELL_TESS, "cornell": N.PT_SCENE_CORNELL, "cornell_glass": N.PT_SCENE_CORNELL_GLASS,
              "soup": N.PT_SCENE_TRIANGLE_SOUP}
     W, H = args.width, args.height
     sd = P.make_scene(kinds[args.scene], args.tris, 0x5EED0001, W, H)
-    r = P.Renderer(P.Window(W, H), device_ordinal=local_rank)
+    r = P.Renderer(P.Window(W, H), device_ordinal=device)
     r.Init()
     t0 = time.time()
     r.SetScene(sd, args.bvh_width)
     commit_s = time.time() - t0
     info = r.BvhInfo()
-    params = P.make_params(W, H, spp=args.spp, max_depth=args.max_depth, rank=rank, nranks=world)
+
+    def mk(**kw):
+        return P.make_params(W, H, spp=kw.pop("spp", args.spp), max_depth=args.max_depth, streams=args.streams, **kw)
+
+    params = mk(rank=rank, nranks=world)
     r.Params = params
     lay = P.tile_layout(params)
     per_rank = lay.tiles_per_rank * lay.floats_per_tile
@@ -88,7 +101,11 @@ def main():
         st = r.Render(0.0)  # synchronous: all kernels of this rank's tiles are done on return
         if world > 1:
             mine = torch.as_tensor(r.TilesDevice(), device="cuda")
-            got = gather_tiles(mine, per_rank, rank, world, dist)  # the one exchange step: tile radiance to rank 0 over xGMI
+            if args.rehearse_gloo:
+                got = gather_tiles(mine.cpu(), per_rank, rank, world, dist)
+                got = got.cuda() if rank == 0 else None
+            else:
+                got = gather_tiles(mine, per_rank, rank, world, dist)  # the one exchange step: tile radiance to rank 0 over xGMI
             if rank == 0:
                 torch.cuda.synchronize()
                 r.AssembleTiles(got.data_ptr(), got.numel())
@@ -99,75 +116,90 @@ def main():
     barrier()
     t0 = time.perf_counter()
     rays = 0
-    gpu_ms = 0.0
     for _ in range(args.steps):
         st = step()
         rays += st.rays
-        gpu_ms += st.gpu_ms
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_choice = {0: "unprobed", 1: "k_extend", 2: "k_extend_packed"}[int(st.reserved[0])]
 
-    tot = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device="cuda")
     if world > 1:
+        dev = "cpu" if args.rehearse_gloo else "cuda"
+        tot = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=dev)
         tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tot.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed, rays_all = float(tmax[0]), float(tsum[1])
     else:
         rays_all = float(rays)
 
+    if world > 1 and args.rehearse_gloo and rank == 0:
+        # the rehearsal also proves the partition: the assembled frame must equal a single-rank frame bit for bit
+        import numpy as np
+        got_img = r.ReadFramebuffer()
+        r.Params = mk()
+        r.Render(0.0)
+        assert np.array_equal(r.ReadFramebuffer(), got_img), "multi-rank frame differs from the single-rank frame"
+        r.Params = params
+
     out = None
     if rank == 0:
-        mrays = rays_all / elapsed / 1e6
+        layout = {2: "BVH2 (64-B nodes)", 4: "BVH4 (128-B nodes)", 68: "BVH4Q (64-B quantised nodes)"}.get(info.width, str(info.width))
+        workload = (f"{args.scene}: {info.n_tris} triangles + {len(sd.sph_mat)} spheres, {layout}, {info.n_nodes} nodes, {W}x{H}, "
+                    f"{args.spp} spp, max depth {args.max_depth}, RR from depth 3, implicit light hits only, {args.streams} sample "
+                    f"streams per pixel; the north_star headline scene (BASELINE configs[4]'s 1M-triangle Cornell at configs[1]'s "
+                    f"1080p/64spp)")
         out = {
-            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene}: {info.n_tris} triangles + {len(sd.sph_mat)} spheres, BVH{info.width} "
-                                   f"({info.n_nodes} nodes), {W}x{H}, {args.spp} spp, max depth {args.max_depth}, "
-                                   f"RR from depth 3, implicit light hits only; BASELINE configs[1]/[2] scene class, the "
-                                   f"north_star headline scene (C5 at 1080p/64spp)",
-                       "rays_per_frame": int(rays_all / args.steps), "bvh_build_s": round(commit_s, 2),
-                       "parallelism": f"tiles{world}"},
+            "metric": "Mrays/s", "value": round(rays_all / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "rays_per_frame": int(rays_all / args.steps), "bvh_build_s": round(commit_s, 2),
+                       "extend_kernel": kernel_choice, "parallelism": f"tiles{world}" + ("-gloo-rehearsal" if args.rehearse_gloo else "")},
         }
 
     # ---- roofline of the dominant kernel (rank 0, untimed extra frames) and CPU baseline
     if rank == 0 and world == 1 and not args.no_roofline:
-        r.Params = P.make_params(W, H, spp=args.spp, max_depth=args.max_depth, flags=N.PT_FLAG_PROFILE_KERNELS)
+        r.Params = mk(flags=N.PT_FLAG_PROFILE_KERNELS)
         sp = r.Render(0.0)
-        cnt_spp = max(1, min(args.spp, 4))
-        r.Params = P.make_params(W, H, spp=cnt_spp, max_depth=args.max_depth, flags=N.PT_FLAG_COUNT_VISITS)
+        r.Params = mk(spp=max(1, min(args.spp, 8)), flags=N.PT_FLAG_COUNT_VISITS)
         sc = r.Render(0.0)
         n_nodes_ray = sc.node_visits / sc.rays
         n_tris_ray = sc.tri_tests / sc.rays
         n_sph_ray = sc.sphere_tests / sc.rays
-        # algorithmic bytes the extend kernel must move per ray (DESIGN.md "Roofline"):
-        #   queue slot 4 + ray 32 (two float4) + hit record 8 + bucket slot 4, + node/triangle/sphere bytes visited
-        b_ray = 48.0 + info.width * 32.0 * n_nodes_ray + 48.0 * n_tris_ray + 16.0 * n_sph_ray
+        node_bytes = 64.0 if info.width in (2, 68) else 128.0
+        # algorithmic bytes the extend kernel must move per ray:
+        #   queue slot 4 + ray 32 (two float4) + hit record 8, + node / triangle / sphere bytes of the visits it makes
+        b_ray = 44.0 + node_bytes * n_nodes_ray + 48.0 * n_tris_ray + 16.0 * n_sph_ray
         launches = sp.extend_launches
-        mean_launch_ms = sp.extend_ms / launches
         achieved = b_ray * sp.rays / (sp.extend_ms * 1e-3) / 1e9
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            if pmc.get("workload_key") == [args.scene, args.tris, W, H, args.spp, args.max_depth, args.streams, info.width]:
+                traffic = {"bytes_per_launch": pmc["extend_bytes_per_launch"], "source": pmc["source"]}
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline"] = {
-            "bound": "hbm", "kernel": f"k_extend<{info.width}>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": f"{kernel_choice}<{info.width}>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable_6290": round(achieved / HBM_ACHIEVABLE_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
             "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(n_nodes_ray, 2), "tris_per_ray": round(n_tris_ray, 2),
-            "spheres_per_ray": round(n_sph_ray, 2), "launches": launches, "mean_launch_ms": round(mean_launch_ms, 4),
-            "rays_per_launch": round(sp.rays / launches, 1), "extend_ms": round(sp.extend_ms, 2), "shade_ms": round(sp.shade_ms, 2),
-            "frame_ms_profiled": round(sp.gpu_ms, 2),
-            "note": "scene+BVH (~%d MB) lives in the 256 MiB Infinity Cache, so measured HBM bytes are far below algorithmic bytes; "
-                    "the kernel is latency-bound on dependent node fetches, not streaming-bound" % ((info.node_bytes + info.tri_bytes) >> 20),
+            "spheres_per_ray": round(n_sph_ray, 2), "launches": launches, "mean_launch_ms": round(sp.extend_ms / launches, 4),
+            "bytes_per_launch": round(b_ray * sp.rays / launches), "rays_per_launch": round(sp.rays / launches, 1),
+            "extend_ms": round(sp.extend_ms, 2), "shade_ms": round(sp.shade_ms, 2), "frame_ms_profiled": round(sp.gpu_ms, 2),
+            "note": "scene+BVH (~%d MB) is resident in L2 / the 256 MiB Infinity Cache, so algorithmic bytes are served on-die and the "
+                    "memory-side counters read far less; the kernel is bound by divergent per-lane node fetches, not by streaming"
+                    % ((info.node_bytes + info.tri_bytes) >> 20),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pto  # checker/baseline only: never on the product path
         osc = pto.Scene(sd, (info.width,) + r.BvhRead())
         cores = pto.lib.pto_num_threads()
-        # bounded sample: same scene and BVH bytes, full 1080p frame, spp chosen for ~cpu-seconds of work
-        probe = P.make_params(W, H // 8, spp=1, max_depth=args.max_depth)
+        # bounded sample: same scene and BVH bytes, full frame, spp chosen for ~cpu-seconds of work
+        probe = P.make_params(W, max(H // 8, 1), spp=1, max_depth=args.max_depth)
         t0 = time.perf_counter(); _, ps = pto.render(osc, probe); dt = time.perf_counter() - t0
-        rate = ps.rays / dt
-        spp_cpu = max(1, min(args.spp, int(args.cpu_seconds * rate / (ps.rays * 8))))
-        cp = P.make_params(W, H, spp=spp_cpu, max_depth=args.max_depth)
+        spp_cpu = max(1, min(args.spp, int(args.cpu_seconds * (ps.rays / dt) / (ps.rays * 8))))
+        cp = P.make_params(W, H, spp=spp_cpu, max_depth=args.max_depth, streams=args.streams)
         t0 = time.perf_counter(); _, cs = pto.render(osc, cp); dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(cs.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
                                "sample": f"same scene + BVH bytes, {W}x{H}, {spp_cpu} spp ({cs.rays} rays, {dt:.1f} s), scalar C oracle, OpenMP over rows"}
