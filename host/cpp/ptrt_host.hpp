@@ -24,7 +24,7 @@ public:
     Renderer(uint32_t width = 1920, uint32_t height = 1080) // App.cs:27
     {
         Params.width = width; Params.height = height; Params.spp = 1; Params.max_depth = 8; Params.rr_start = 3;
-        Params.seed = 0x5EED0001u; Params.mode = PT_REFERENCE_SPHERE; Params.ray_eps = 1e-4f; Params.nranks = 1;
+        Params.seed = 0x5EED0001u; Params.mode = PT_REFERENCE_SPHERE; Params.ray_eps = 1e-4f; Params.nranks = 1; Params.streams = 8;
     }
     Renderer(const Renderer &) = delete;
     ~Renderer() { Dispose(); }

@@ -17,7 +17,7 @@ public unsafe class HipRenderer : IDisposable
     {
         Width = width; Height = height;
         Params = new PtRenderParams { Width = width, Height = height, Spp = 1, MaxDepth = 8, RrStart = 3, Seed = 0x5EED0001,
-                                      Mode = (uint)PtMode.ReferenceSphere, RayEps = 1e-4f, NRanks = 1 };
+                                      Mode = (uint)PtMode.ReferenceSphere, RayEps = 1e-4f, NRanks = 1, Streams = 8 };
     }
 
     // Renderer.Init (Renderer.cs:66-84): device + resources + compute pipeline

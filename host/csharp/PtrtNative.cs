@@ -17,7 +17,7 @@ public enum PtSceneKind : uint { Cornell = 0, CornellGlass = 1, TriangleSoup = 2
 [StructLayout(LayoutKind.Sequential)] public unsafe struct PtRenderParams
 {
     public uint Width, Height, Spp, MaxDepth, RrStart, Seed, SampleOffset, Mode;
-    public float RayEps; public uint Rank, NRanks, TileSize, Flags; public fixed uint Pad[3];
+    public float RayEps; public uint Rank, NRanks, TileSize, Flags, Streams; public fixed uint Pad[2];
 }
 [StructLayout(LayoutKind.Sequential)] public unsafe struct PtStats
 {

@@ -113,11 +113,11 @@ typedef struct {
 } pt_stats;
 
 typedef struct {
-    uint32_t width;          /* 2 or 4 */
+    uint32_t width;          /* the layout id the scene was committed with: PT_BVH_WIDTH_2, _4 or _4Q */
     uint32_t n_nodes;
     uint32_t n_tris;
     uint32_t max_depth;
-    uint64_t node_bytes;     /* n_nodes * width * 32 */
+    uint64_t node_bytes;     /* n_nodes * 64 (layouts 2 and 4Q) or n_nodes * 128 (layout 4) */
     uint64_t tri_bytes;      /* n_tris * 48 */
     double build_ms;
     float sah_cost;

@@ -156,6 +156,19 @@ def test_c1_golden_pin(P, pto):
     assert (img[..., 3] == 1.0).all()
 
 
+def test_sample_streams_in_the_oracle(P, pto):
+    """SPEC §5: K partial sums per pixel. K = 0/1 is the plain sequential sum; other K only reassociate float additions."""
+    sd = P.make_scene(0, 0, 1, 48, 48)
+    a, sa = pto.render(pto.Scene(sd), P.make_params(48, 48, spp=9, max_depth=5, streams=1))
+    z, _ = pto.render(pto.Scene(sd), P.make_params(48, 48, spp=9, max_depth=5, streams=0))
+    assert np.array_equal(a, z)
+    for k in (2, 4, 16):
+        b, sb = pto.render(pto.Scene(sd), P.make_params(48, 48, spp=9, max_depth=5, streams=k))
+        assert sb.rays == sa.rays and np.abs(a - b).max() < 2e-6 and (b[..., 3] == 1).all()
+    with pytest.raises(RuntimeError):
+        pto.render(pto.Scene(sd), P.make_params(48, 48, spp=2, streams=17))
+
+
 def test_threads_do_not_change_the_image(P, pto):
     sd = P.make_scene(0, 0, 1, 48, 48)
     p = P.make_params(48, 48, spp=2, max_depth=5)
