@@ -379,7 +379,7 @@ static void trace_pixel(const pto_scene *s, const pto_params *p, uint32_t x, uin
     memset(accs, 0, sizeof accs);
     uint32_t pixel = y * p->width + x;
     for (uint32_t si = 0; si < p->spp; ++si) {
-        float *acc = accs[si % K];
+        float *acc = accs[(p->sample_offset + si) % K];
         uint32_t key = pto_path_key(p->seed, pixel, p->sample_offset + si);
         float of[3], df[3];
         pto_camera_ray(&s->cam, x, y, key, of, df);

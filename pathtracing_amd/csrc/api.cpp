@@ -52,7 +52,10 @@ struct pt_context {
     bool own_stream = false;
     std::string err;
     // path state
-    DevBuf<float4> ray_o, ray_d, thr, acc, fb;
+    DevBuf<float4> ray_o, ray_d, thr, acc, tiles, fb;
+    // what the partial sums in `acc` currently hold (PT_FLAG_ACCUMULATE continues them): frame geometry and samples so far
+    uint32_t acc_w = 0, acc_h = 0, acc_rank = 0, acc_nranks = 0, acc_streams = 0, acc_seed = 0;
+    uint64_t acc_spp = 0;
     DevBuf<float2> hit;
     DevBuf<uint32_t> sd, q_ext0, q_ext1, q_b[B_COUNT], counters, fb8;
     DevBuf<int32_t> stack_ovf;
@@ -180,7 +183,7 @@ void pt_context_destroy(pt_context *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    c->ray_o.release(); c->ray_d.release(); c->thr.release(); c->acc.release(); c->fb.release(); c->hit.release();
+    c->ray_o.release(); c->ray_d.release(); c->thr.release(); c->acc.release(); c->tiles.release(); c->fb.release(); c->hit.release();
     c->sd.release(); c->q_ext0.release(); c->q_ext1.release(); c->counters.release(); c->fb8.release(); c->stack_ovf.release();
     for (auto &q : c->q_b) q.release();
     if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -429,7 +432,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     const uint32_t n_slots = (uint32_t)slots64;
 
     HIP_TRY(c, c->ray_o.ensure(n_slots)); HIP_TRY(c, c->ray_d.ensure(n_slots)); HIP_TRY(c, c->thr.ensure(n_slots));
-    HIP_TRY(c, c->acc.ensure(n_slots)); HIP_TRY(c, c->hit.ensure(n_slots)); HIP_TRY(c, c->sd.ensure(n_slots));
+    HIP_TRY(c, c->acc.ensure(n_slots)); HIP_TRY(c, c->tiles.ensure(pixel_slots)); HIP_TRY(c, c->hit.ensure(n_slots)); HIP_TRY(c, c->sd.ensure(n_slots));
     // every queue = kShards regions of shard_cap entries; shard s owns the 256-slot groups g with g % kShards == s
     const uint32_t groups = n_slots / kBlock, shard_cap = ((groups + kShards - 1) / kShards) * kBlock;
     const size_t q_entries = (size_t)kShards * shard_cap;
@@ -450,6 +453,18 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     fp.seed_hashed = host_pcg(p->seed); fp.sample_offset = p->sample_offset; fp.ray_eps = p->ray_eps;
     fp.rank = p->rank; fp.nranks = nranks; fp.tiles_x = lay.tiles_x; fp.n_tiles = lay.n_tiles;
     fp.streams = streams; fp.slots_per_stream = pixel_slots;
+    // progressive accumulation (the reference re-renders every frame, App.cs:39-42; this is its converging analogue):
+    // keep the stream partials of the previous call(s) and divide by the total number of samples at the end
+    const bool accumulate = (p->flags & PT_FLAG_ACCUMULATE) != 0;
+    if (accumulate) {
+        if (c->acc_spp == 0 || c->acc_w != p->width || c->acc_h != p->height || c->acc_rank != p->rank || c->acc_nranks != nranks ||
+            c->acc_streams != streams || c->acc_seed != p->seed)
+            return fail(c, PT_ERR_INVALID_ARGUMENT, "PT_FLAG_ACCUMULATE needs a previous frame with the same size, rank, nranks, streams and seed");
+        if (p->sample_offset != c->acc_spp) return fail(c, PT_ERR_INVALID_ARGUMENT, "PT_FLAG_ACCUMULATE: sample_offset must be %llu (samples so far)", (unsigned long long)c->acc_spp);
+    }
+    fp.accumulate = accumulate ? 1u : 0u;
+    const uint64_t total_spp = (accumulate ? c->acc_spp : 0u) + p->spp;
+    c->acc_spp = 0; // invalid until this frame completes
 
     const DeviceScene &sc = s->ds;
     hipStream_t q = c->stream;
@@ -516,9 +531,9 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             }
         }
     }
-    if (streams > 1) HIP_TRY(c, launch_reduce_streams(q, c->acc.p, pixel_slots, streams)); // plane 0 = the pixel sums = the gather payload
+    HIP_TRY(c, launch_reduce_streams(q, c->acc.p, c->tiles.p, pixel_slots, streams)); // tiles = the pixel sums = the gather payload
     if (nranks == 1)
-        HIP_TRY(c, launch_assemble(q, c->acc.p, 1, pixel_slots, p->width, p->height, lay.tiles_x, lay.n_tiles, 1.0f / (float)p->spp, c->fb.p, c->fb8.p));
+        HIP_TRY(c, launch_assemble(q, c->tiles.p, 1, pixel_slots, p->width, p->height, lay.tiles_x, lay.n_tiles, 1.0f / (float)total_spp, c->fb.p, c->fb8.p));
     HIP_TRY(c, hipEventRecord(c->ev_stop, q));
     HIP_TRY(c, hipMemcpyAsync(c->h_counts + (size_t)kLag * kRingWords, c->counters.p, sizeof(uint32_t) * kCntTotalWords, hipMemcpyDeviceToHost, q));
     HIP_TRY(c, hipStreamSynchronize(q));
@@ -554,6 +569,8 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
         out.other_ms = out.gpu_ms - out.extend_ms - out.shade_ms;
     }
     c->n_slots = pixel_slots;
+    c->acc_w = p->width; c->acc_h = p->height; c->acc_rank = p->rank; c->acc_nranks = nranks; c->acc_streams = streams; c->acc_seed = p->seed;
+    c->acc_spp = total_spp;
     c->fb_valid = (nranks == 1);
     if (stats) *stats = out;
     return PT_OK;
@@ -596,7 +613,7 @@ pt_status pt_tiles_device_ptr(pt_context *c, void **dptr, uint64_t *n_floats)
 {
     if (!c || !dptr) return fail(c, PT_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!c->n_slots) return fail(c, PT_ERR_NOT_COMMITTED, "no path-traced frame yet");
-    *dptr = c->acc.p;
+    *dptr = c->tiles.p;
     if (n_floats) *n_floats = (uint64_t)c->n_slots * 4;
     return PT_OK;
 }
@@ -614,7 +631,7 @@ pt_status pt_assemble_tiles(pt_context *c, const pt_render_params *p, const void
     HIP_TRY(c, hipSetDevice(c->device));
     if ((st = ensure_frame(c, p->width, p->height)) != PT_OK) return st;
     HIP_TRY(c, launch_assemble(c->stream, (const float4 *)gathered, nranks, (uint32_t)per_rank, p->width, p->height, lay.tiles_x, lay.n_tiles,
-                               1.0f / (float)p->spp, c->fb.p, c->fb8.p));
+                               1.0f / (float)(((p->flags & PT_FLAG_ACCUMULATE) ? (uint64_t)p->sample_offset : 0u) + p->spp), c->fb.p, c->fb8.p));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->fb_valid = true;
     return PT_OK;

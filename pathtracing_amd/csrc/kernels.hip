@@ -1,15 +1,19 @@
 // kernels.hip — gfx950 wavefront kernels of libptrt (docs/SPEC.md; DESIGN.md "Kernels").
 //
 //   k_reference_sphere : the reference's CSMain (Test.hlsl:1-40; dispatch Renderer.cs:1020), one lane = one pixel
-//   k_generate         : camera rays for sample 0 of every owned pixel, fills the extend queues
-//   k_extend<N>        : ray -> closest hit. BVH-N traversal, stack in LDS ([level][lane], conflict-free),
-//                        spheres by scalar loads, hits bucketed by material kind with one atomic per wave
-//   k_shade            : emission, BSDF sample, Russian roulette, accumulate, in-place regeneration of the
-//                        next sample of the same pixel; survivors are compacted into the next extend queue
+//   k_generate         : camera ray of the first sample of every (owned pixel, sample stream), fills the extend queues
+//   k_extend<L>        : ray -> closest hit. BVH traversal for node layout L, stack in LDS ([level][lane],
+//                        conflict-free), spheres by scalar loads, one 4-row fetch per step for node or triangle
+//   k_extend_packed<L> : the same, with ballot/mbcnt refill of idle lanes from a per-wave chunk of the queue
+//   k_shade<false>     : walks the extend queue: miss / Lambert shaded in place (emission, BSDF sample, Russian
+//                        roulette, accumulate, in-place regeneration of the stream's next sample), specular hits
+//                        deferred to per-kind bucket queues; survivors are compacted into the next extend queue
+//   k_shade<true>      : the metal / dielectric buckets
+//   k_reduce_streams   : fixed-order sum of a pixel's stream partials
 //   k_assemble         : tile-major slots (of 1..R ranks) -> row-major float4 + RGBA8 frame
 //
-// One slot per owned pixel, at most one live path per slot => framebuffer RMW without atomics and a
-// per-pixel summation order identical to the oracle's `for s in 0..spp`.
+// One slot per (owned pixel, stream), at most one live path per slot => accumulator RMW without atomics and a
+// per-stream summation order identical to the oracle's.
 // Queues are split into kShards static shards (ptrt_internal.h): blockIdx.y = shard, and every lane of a block only
 // ever sees slots of its own shard, so a wavefront's push goes to exactly one per-shard counter.
 #include "ptrt_internal.h"
@@ -82,17 +86,19 @@ __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState p
     const uint32_t slot = (((j >> 8) * kShards + shard) << 8) | (j & 255u);
     uint32_t x = 0, y = 0;
     const bool in_range = j < ps.shard_cap && slot < ps.n_slots;
-    const uint32_t stream = slot / fp.slots_per_stream; // first sample of stream k is sample k
-    const bool valid = in_range && stream < fp.spp && slot_pixel(slot, fp, x, y);
-    if (in_range) ps.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // stream k takes the samples s with (sample_offset + s) % K == k, in increasing s (docs/SPEC.md §5)
+    const uint32_t stream = slot / fp.slots_per_stream;
+    const uint32_t first = (stream + fp.streams - fp.sample_offset % fp.streams) % fp.streams;
+    const bool valid = in_range && first < fp.spp && slot_pixel(slot, fp, x, y);
+    if (in_range && !fp.accumulate) ps.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) {
-        const uint32_t key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset + stream);
+        const uint32_t key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset + first);
         V3 o, d;
         camera_ray_of(sc.cam, x, y, key, o, d);
         ps.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
         ps.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
         ps.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(key));
-        ps.sd[slot] = stream << 8;
+        ps.sd[slot] = first << 8;
     }
     wave_push(&ps.counters[cnt_ext_index(0, shard)], ps.q_ext[0] + (size_t)shard * ps.shard_cap, valid, slot);
 }
@@ -489,8 +495,10 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sum of a pixel's K stream partials in the fixed order ((s0 + s1) + s2) + ... (docs/SPEC.md §5), into plane 0.
-__global__ void __launch_bounds__(kBlock) k_reduce_streams(float4 *__restrict__ acc, uint32_t slots_per_stream, uint32_t streams)
+// Sum of a pixel's K stream partials in the fixed order ((s0 + s1) + s2) + ... (docs/SPEC.md §5) into the tile-major
+// buffer that is assembled / gathered. The partials themselves stay intact so that a later frame can keep accumulating.
+__global__ void __launch_bounds__(kBlock) k_reduce_streams(const float4 *__restrict__ acc, float4 *__restrict__ tiles,
+                                                           uint32_t slots_per_stream, uint32_t streams)
 {
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= slots_per_stream) return;
@@ -499,7 +507,7 @@ __global__ void __launch_bounds__(kBlock) k_reduce_streams(float4 *__restrict__ 
         const float4 a = acc[(size_t)k * slots_per_stream + slot];
         t.x = t.x + a.x; t.y = t.y + a.y; t.z = t.z + a.z; t.w = t.w + a.w;
     }
-    acc[slot] = t;
+    tiles[slot] = t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -576,9 +584,9 @@ hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &p
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_streams(hipStream_t s, float4 *acc, uint32_t slots_per_stream, uint32_t streams)
+hipError_t launch_reduce_streams(hipStream_t s, const float4 *acc, float4 *tiles, uint32_t slots_per_stream, uint32_t streams)
 {
-    hipLaunchKernelGGL(k_reduce_streams, dim3(blocks_for(slots_per_stream)), dim3(kBlock), 0, s, acc, slots_per_stream, streams);
+    hipLaunchKernelGGL(k_reduce_streams, dim3(blocks_for(slots_per_stream)), dim3(kBlock), 0, s, acc, tiles, slots_per_stream, streams);
     return hipGetLastError();
 }
 

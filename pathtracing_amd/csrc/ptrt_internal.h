@@ -81,6 +81,7 @@ struct FrameParams {
     uint32_t rank, nranks, tiles_x, n_tiles;
     uint32_t streams;          // K sample streams per pixel (docs/SPEC.md §5); slot = stream * slots_per_stream + pixel slot
     uint32_t slots_per_stream; // pixel slots of this rank (tiles_per_rank * 4096)
+    uint32_t accumulate;       // PT_FLAG_ACCUMULATE: keep the partial sums of the previous frame(s)
 };
 
 // kernel launchers (kernels.hip). All enqueue on `s` and return the launch error.
@@ -89,7 +90,7 @@ hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4
 hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp);
 hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count, uint32_t packed_chunk);
 hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, bool specular);
-hipError_t launch_reduce_streams(hipStream_t s, float4 *acc, uint32_t slots_per_stream, uint32_t streams);
+hipError_t launch_reduce_streams(hipStream_t s, const float4 *acc, float4 *tiles, uint32_t slots_per_stream, uint32_t streams);
 hipError_t launch_assemble(hipStream_t s, const float4 *gathered, uint32_t nranks, uint32_t slots_per_rank,
                            uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, float inv_spp,
                            float4 *fb, uint32_t *fb8);

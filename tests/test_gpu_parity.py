@@ -173,6 +173,32 @@ def test_sample_streams(P, pto, renderer, streams):
     assert np.array_equal(renderer.ReadFramebuffer(), want)
 
 
+def test_progressive_accumulation(P, pto, renderer):
+    """PT_FLAG_ACCUMULATE (the analogue of the reference's per-frame loop App.cs:39-42): three calls of
+    3 + 5 + 2 samples show exactly the frame of one 10-sample call, for 1 and 4 streams."""
+    N = P.native
+    sd = P.make_scene(N.PT_SCENE_CORNELL_GLASS, 0, 9, 120, 90)
+    renderer.SetScene(sd, 0)
+    for streams in (1, 4):
+        done = 0
+        for n in (3, 5, 2):
+            renderer.Params = P.make_params(120, 90, spp=n, max_depth=8, streams=streams, sample_offset=done,
+                                            flags=N.PT_FLAG_ACCUMULATE if done else 0)
+            renderer.Render(0.0)
+            done += n
+        img = renderer.ReadFramebuffer()
+        info = renderer.BvhInfo()
+        ref, _ = pto.render(pto.Scene(sd, (info.width,) + renderer.BvhRead()), P.make_params(120, 90, spp=10, max_depth=8, streams=streams))
+        assert np.array_equal(img, ref)
+    # a frame that does not continue the previous one is refused
+    renderer.Params = P.make_params(120, 90, spp=2, streams=4, sample_offset=3, flags=N.PT_FLAG_ACCUMULATE)
+    with pytest.raises(P.PtException, match="sample_offset"):
+        renderer.Render(0.0)
+    renderer.Params = P.make_params(64, 64, spp=2, streams=4, sample_offset=10, flags=N.PT_FLAG_ACCUMULATE)
+    with pytest.raises(P.PtException, match="previous frame"):
+        renderer.Render(0.0)
+
+
 def test_edge_cases(P, pto, renderer):
     N = P.native
     cam = P.make_scene(0, 0, 0, 70, 40).cam
