@@ -98,7 +98,7 @@ typedef struct {
     uint32_t flags;          /* PT_FLAG_* */
     uint32_t streams;        /* sample streams per pixel kept in flight at once (docs/SPEC.md §5): sample s goes to stream
                                 s mod streams, each stream has its own partial sum, the pixel is their fixed-order sum.
-                                0 = 1; at most 16. More streams = more rays per wavefront iteration, same picture definition. */
+                                0 = 1; at most 64. More streams = more rays per wavefront iteration, same picture definition. */
     uint32_t pad[2];
 } pt_render_params; /* 64 B */
 

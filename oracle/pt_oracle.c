@@ -368,7 +368,7 @@ int pto_bsdf_sample(const pto_material *m, const float dv[3], const float nv[3],
     return 1;
 }
 
-#define PTO_MAX_STREAMS 16
+#define PTO_MAX_STREAMS 64
 static uint32_t stream_count(const pto_params *p) { return p->streams ? p->streams : 1u; }
 
 static void trace_pixel(const pto_scene *s, const pto_params *p, uint32_t x, uint32_t y, float out[4], pto_stats *st)

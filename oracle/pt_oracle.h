@@ -34,7 +34,7 @@ typedef struct { float origin[3], forward[3], right[3], up[3]; float scale, cx, 
 typedef struct {
     uint32_t width, height, spp, max_depth, rr_start, seed, sample_offset, mode;
     float ray_eps; uint32_t rank, nranks, tile_size, flags;
-    uint32_t streams; /* partial sums per pixel (SPEC §5); 0 = 1, at most 16 */
+    uint32_t streams; /* partial sums per pixel (SPEC §5); 0 = 1, at most 64 */
     uint32_t pad[2];
 } pto_params; /* 64 B, same layout as pt_render_params */
 

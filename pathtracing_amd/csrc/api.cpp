@@ -423,7 +423,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     if (p->max_depth == 0 || p->max_depth > 255) return fail(c, PT_ERR_INVALID_ARGUMENT, "max_depth must be in [1,255]");
     if (!std::isfinite(p->ray_eps) || p->ray_eps < 0.f) return fail(c, PT_ERR_INVALID_ARGUMENT, "ray_eps must be finite and >= 0");
 
-    if (p->streams > 16) return fail(c, PT_ERR_INVALID_ARGUMENT, "streams must be in [0,16]");
+    if (p->streams > 64) return fail(c, PT_ERR_INVALID_ARGUMENT, "streams must be in [0,64]");
     const uint32_t nranks = p->nranks ? p->nranks : 1u;
     const uint32_t streams = p->streams ? p->streams : 1u;
     const uint32_t pixel_slots = lay.tiles_per_rank * kTilePixels;              // one slot per owned pixel ...

@@ -151,7 +151,7 @@ def test_rank_partition_is_image_invariant(P, pto, renderer):
         assert np.array_equal(renderer.ReadFramebuffer(), want), nranks
 
 
-@pytest.mark.parametrize("streams", [2, 4, 7])
+@pytest.mark.parametrize("streams", [2, 4, 7, 40])
 def test_sample_streams(P, pto, renderer, streams):
     """SPEC §5: K sample streams per pixel in flight, each with its own partial sum, summed in fixed order.
     The oracle forms the same partial sums, so the picture stays bit-identical for every K (also K > spp, K not dividing spp)."""

@@ -162,11 +162,11 @@ def test_sample_streams_in_the_oracle(P, pto):
     a, sa = pto.render(pto.Scene(sd), P.make_params(48, 48, spp=9, max_depth=5, streams=1))
     z, _ = pto.render(pto.Scene(sd), P.make_params(48, 48, spp=9, max_depth=5, streams=0))
     assert np.array_equal(a, z)
-    for k in (2, 4, 16):
+    for k in (2, 4, 16, 64):
         b, sb = pto.render(pto.Scene(sd), P.make_params(48, 48, spp=9, max_depth=5, streams=k))
         assert sb.rays == sa.rays and np.abs(a - b).max() < 2e-6 and (b[..., 3] == 1).all()
     with pytest.raises(RuntimeError):
-        pto.render(pto.Scene(sd), P.make_params(48, 48, spp=2, streams=17))
+        pto.render(pto.Scene(sd), P.make_params(48, 48, spp=2, streams=65))
 
 
 def test_threads_do_not_change_the_image(P, pto):
