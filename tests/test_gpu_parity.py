@@ -128,6 +128,18 @@ def test_1m_triangles_full_hd_properties(P, pto, renderer):
     assert rmse(img, ref) <= RMSE_TOL and np.array_equal(img, ref)
 
 
+def test_4k_frame_and_full_hd_soup(P, pto, renderer):
+    """BASELINE configs[4] frame size (3840x2160, 1M-triangle Cornell) and configs[2] (1M-triangle soup, 1080p) at 1 spp,
+    8 streams allocated: the largest slot spaces the benchmark configurations use, against the oracle."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_TESS, 1 << 20, 0x5EED0001, 3840, 2160)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(3840, 2160, spp=1, max_depth=8, streams=8), 0)
+    assert_parity(img, st, ref, ost)
+    assert st.paths == 3840 * 2160 and (img[..., 3] == 1.0).all()
+    sd = P.make_scene(P.native.PT_SCENE_TRIANGLE_SOUP, 1 << 20, 0x5EED0001, 1920, 1080)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(1920, 1080, spp=1, max_depth=8, streams=8), 0)
+    assert_parity(img, st, ref, ost)
+
+
 def test_rank_partition_is_image_invariant(P, pto, renderer):
     """SPEC §6: the picture must not depend on the number of ranks. Two 'ranks' rendered one after the other on this GPU,
     concatenated as a gather would, assembled by pt_assemble_tiles == the single-rank frame, bit for bit."""
