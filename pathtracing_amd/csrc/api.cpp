@@ -284,6 +284,9 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
 {
     if (!s) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "scene is NULL");
     pt_context *c = s->ctx;
+    const bool lbvh = (bvh_width & PT_BVH_BUILD_LBVH) != 0; // hierarchy built on the GPU instead of the host SAH builder
+    bvh_width &= ~(uint32_t)PT_BVH_BUILD_LBVH;
+    if (lbvh && !c) return fail(c, PT_ERR_UNSUPPORTED, "PT_BVH_BUILD_LBVH needs a device context (detached scenes use the host builder)");
     if (bvh_width == PT_BVH_WIDTH_DEFAULT) bvh_width = PT_BVH_WIDTH_4Q;
     if (bvh_width != PT_BVH_WIDTH_2 && bvh_width != PT_BVH_WIDTH_4 && bvh_width != PT_BVH_WIDTH_4Q)
         return fail(c, PT_ERR_INVALID_ARGUMENT, "bvh_width must be one of PT_BVH_WIDTH_* (0, 2, 4, 68)");
@@ -293,7 +296,13 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     for (uint32_t i = 0; i < nt; ++i) if (s->tri_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "triangle %u: material id %u >= %u", i, s->tri_mat[i], nm);
     for (uint32_t i = 0; i < ns; ++i) if (s->sph_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "sphere %u: material id %u >= %u", i, s->sph_mat[i], nm);
 
-    build_bvh(s->verts.data(), s->tri_mat.data(), nt, bvh_width == PT_BVH_WIDTH_2 ? 2u : 4u, s->bvh);
+    const uint32_t fan = bvh_width == PT_BVH_WIDTH_2 ? 2u : 4u;
+    if (lbvh && nt >= 2) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        BinaryBvh bt;
+        HIP_TRY(c, build_lbvh_device(c->stream, s->verts.data(), nt, bt));
+        build_bvh_from_binary(bt, s->verts.data(), s->tri_mat.data(), nt, fan, s->bvh);
+    } else build_bvh(s->verts.data(), s->tri_mat.data(), nt, fan, s->bvh);
     if (s->bvh.max_depth > 90) return fail(c, PT_ERR_INTERNAL, "BVH depth %u exceeds the supported 90", s->bvh.max_depth);
     s->layout = bvh_width;
     s->packed_nodes.clear();

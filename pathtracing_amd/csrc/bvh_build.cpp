@@ -112,33 +112,11 @@ struct Builder {
     }
 };
 
-} // namespace
-
-void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out)
+// Binary tree (tmp nodes, leaves = ranges of idx) -> blob: collapse to `width` children per node by opening the child of
+// largest area, lay nodes out breadth-first, emit triangles in leaf order, compute depth and the worst-case stack need.
+void emit_blob(const std::vector<Tmp> &tn, int32_t root, const std::vector<uint32_t> &idx, const float *verts9, const uint32_t *mats,
+               uint32_t n_tris, uint32_t width, BvhBlob &out)
 {
-    const auto t0 = std::chrono::steady_clock::now();
-    out = BvhBlob{};
-    out.width = width;
-    if (n_tris == 0) return;
-
-    std::vector<Prim> prims(n_tris);
-    std::vector<uint32_t> idx(n_tris);
-    for (uint32_t i = 0; i < n_tris; ++i) {
-        const float *p = verts9 + (size_t)i * 9;
-        Prim &pr = prims[i];
-        for (int k = 0; k < 3; ++k) {
-            const float lo = std::min(p[k], std::min(p[3 + k], p[6 + k])), hi = std::max(p[k], std::max(p[3 + k], p[6 + k]));
-            pr.box.lo[k] = lo - pad_of(lo);
-            pr.box.hi[k] = hi + pad_of(hi);
-            pr.c[k] = 0.5f * (lo + hi);
-        }
-        idx[i] = i;
-    }
-    Builder B(prims, idx);
-    const int32_t root = B.build(0, n_tris, 0);
-    const std::vector<Tmp> &tn = B.nodes;
-
-    // ---- emit: breadth-first over output nodes
     struct Pending { int32_t kids[4]; int nk; };
     std::vector<Pending> pend;
     pend.reserve(tn.size());
@@ -207,7 +185,77 @@ void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint3
     }
     out.max_depth = depth[0];
     out.stack_need = need[0];
+}
+
+} // namespace
+
+void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    out = BvhBlob{};
+    out.width = width;
+    if (n_tris == 0) return;
+
+    std::vector<Prim> prims(n_tris);
+    std::vector<uint32_t> idx(n_tris);
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        const float *p = verts9 + (size_t)i * 9;
+        Prim &pr = prims[i];
+        for (int k = 0; k < 3; ++k) {
+            const float lo = std::min(p[k], std::min(p[3 + k], p[6 + k])), hi = std::max(p[k], std::max(p[3 + k], p[6 + k]));
+            pr.box.lo[k] = lo - pad_of(lo);
+            pr.box.hi[k] = hi + pad_of(hi);
+            pr.c[k] = 0.5f * (lo + hi);
+        }
+        idx[i] = i;
+    }
+    Builder B(prims, idx);
+    const int32_t root = B.build(0, n_tris, 0);
+    emit_blob(B.nodes, root, idx, verts9, mats, n_tris, width, out);
     out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// A binary LBVH built on the device (lbvh.hip) -> blob. Subtrees of at most kMaxLeaf triangles become leaves (their
+// triangles are contiguous in Morton order), everything else keeps the device's topology and boxes.
+void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    out = BvhBlob{};
+    out.width = width;
+    if (n_tris < 2 || bt.order.size() != n_tris) return;
+    std::vector<Tmp> tn;
+    tn.reserve((size_t)n_tris * 2);
+    // iterative DFS from the root (deep LBVH chains stay off the C stack); tn grows, so child links are patched by index
+    int32_t root = -1;
+    struct Work { int32_t node; int32_t parent; int side; };
+    std::vector<Work> work;
+    work.push_back({ 0, -1, 0 });
+    while (!work.empty()) {
+        const Work w = work.back(); work.pop_back();
+        Tmp t; t.left = t.right = -1; t.first = 0; t.count = 0;
+        if (w.node >= 0) {
+            const uint32_t f = bt.first[w.node], l = bt.last[w.node], cnt = l - f + 1;
+            for (int k = 0; k < 3; ++k) { t.box.lo[k] = bt.box[(size_t)w.node * 6 + k]; t.box.hi[k] = bt.box[(size_t)w.node * 6 + 3 + k]; }
+            if (cnt <= kMaxLeaf) { t.first = f; t.count = cnt; }
+        } else { // single-triangle leaf: its padded box is recomputed here exactly as the device did
+            const uint32_t j = (uint32_t)~w.node, id = bt.order[j];
+            const float *p = verts9 + (size_t)id * 9;
+            for (int k = 0; k < 3; ++k) {
+                const float lo = std::min(p[k], std::min(p[3 + k], p[6 + k])), hi = std::max(p[k], std::max(p[3 + k], p[6 + k]));
+                t.box.lo[k] = lo - pad_of(lo); t.box.hi[k] = hi + pad_of(hi);
+            }
+            t.first = j; t.count = 1;
+        }
+        const int32_t me = (int32_t)tn.size();
+        tn.push_back(t);
+        if (w.parent < 0) root = me; else if (w.side == 0) tn[w.parent].left = me; else tn[w.parent].right = me;
+        if (w.node >= 0 && t.count == 0) {
+            work.push_back({ bt.right[w.node], me, 1 });
+            work.push_back({ bt.left[w.node], me, 0 });
+        }
+    }
+    emit_blob(tn, root, bt.order, verts9, mats, n_tris, width, out);
+    out.build_ms = bt.device_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 // ---- BVH4Q: 64-byte nodes, child boxes quantised to 8 bits per coordinate on a per-node power-of-two grid

@@ -21,6 +21,17 @@ struct BvhBlob {
 // verts9: 9 floats per triangle; mats may be null (all 0). width: 2 or 4.
 void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out);
 
+// Binary LBVH as the device builder (lbvh.hip) returns it: n leaves of one triangle each in Morton order, n-1 internal nodes, node 0 = root.
+struct BinaryBvh {
+    std::vector<uint32_t> order;        // triangle index of leaf j
+    std::vector<int32_t> left, right;   // children of internal node i: >= 0 internal node, < 0 leaf ~j
+    std::vector<uint32_t> first, last;  // leaf range [first, last] covered by internal node i
+    std::vector<float> box;             // 6 floats per internal node: union of the padded triangle boxes below it
+    double device_ms = 0.0;             // upload + kernels + sort + read-back
+};
+// pack a device-built binary tree into a width-2/4 blob (subtrees of <= 4 triangles become leaves)
+void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out);
+
 // BVH4Q (layout id 68): repack a width-4 blob into 64-byte nodes with 8-bit child boxes:
 //   +0 origin f32[3] | +12 exponent u8[3],0 | +16 ref i32[4] | +32 qlo_x,qlo_y,qlo_z u8[4] each | +44 qhi_x,qhi_y,qhi_z | +56 pad
 void quantize_bvh4(const BvhBlob &in, std::vector<uint8_t> &out);

@@ -95,4 +95,8 @@ hipError_t launch_assemble(hipStream_t s, const float4 *gathered, uint32_t nrank
                            uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, float inv_spp,
                            float4 *fb, uint32_t *fb8);
 
+// lbvh.hip: Morton sort + Karras hierarchy + refit on the device; returns the binary tree on the host
+struct BinaryBvh;
+hipError_t build_lbvh_device(hipStream_t s, const float *verts9, uint32_t n_tris, BinaryBvh &out);
+
 } // namespace ptrt

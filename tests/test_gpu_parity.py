@@ -140,6 +140,28 @@ def test_4k_frame_and_full_hd_soup(P, pto, renderer):
     assert_parity(img, st, ref, ost)
 
 
+@pytest.mark.parametrize("layout", [2, 4, 68])
+def test_gpu_lbvh_builder(P, pto, renderer, layout):
+    """hierarchy built on the GPU (Morton sort + Karras + refit). The blob must pass the oracle's structural
+    validator, the HIP frame must equal the oracle traversing THOSE bytes (rays and visit counts included), and — because the
+    closest hit does not depend on the tree (SPEC §4) — it must equal the frame of the host-SAH-built scene bit for bit."""
+    N = P.native
+    for kind, detail in ((N.PT_SCENE_TRIANGLE_SOUP, 40000), (N.PT_SCENE_CORNELL_TESS, 30000), (N.PT_SCENE_CORNELL, 0)):
+        sd = P.make_scene(kind, detail, 11, 160, 100)
+        p = P.make_params(160, 100, spp=3, max_depth=6, streams=2)
+        sah_img, sah_st, _, _ = run_both(P, pto, renderer, sd, p, layout)
+        img, st, ref, ost = run_both(P, pto, renderer, sd, p, layout | N.PT_BVH_BUILD_LBVH, count=True)  # run_both validates the blob
+        assert_parity(img, st, ref, ost)
+        assert (st.node_visits, st.tri_tests) == (ost.node_visits, ost.tri_tests)
+        assert st.rays == sah_st.rays and np.array_equal(img, sah_img)
+    # degenerate input: every centroid identical (all Morton codes equal) still yields a valid, bounded-depth tree
+    sd = P.make_scene(N.PT_SCENE_TRIANGLE_SOUP, 3000, 11, 64, 64)
+    sd.verts[:] = sd.verts[0]
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(64, 64, spp=1, max_depth=3), layout | N.PT_BVH_BUILD_LBVH)
+    assert_parity(img, st, ref, ost)
+    assert renderer.BvhInfo().max_depth <= 16
+
+
 def test_rank_partition_is_image_invariant(P, pto, renderer):
     """SPEC §6: the picture must not depend on the number of ranks. Two 'ranks' rendered one after the other on this GPU,
     concatenated as a gather would, assembled by pt_assemble_tiles == the single-rank frame, bit for bit."""

@@ -27,5 +27,5 @@ for name in which:
         info = r.BvhInfo()
         print(f"{name:8s} bvh{width} rays {best.rays/1e6:8.1f}M  {best.gpu_ms:8.2f} ms  {best.rays/best.gpu_ms/1e3:8.1f} Mrays/s  "
               f"iters {best.iterations:4d} extend {pr.extend_ms:7.2f} shade {pr.shade_ms:7.2f} other {pr.other_ms:6.2f}  "
-              f"nodes/ray {c.node_visits/c.rays:6.2f} tris/ray {c.tri_tests/c.rays:5.2f} depth {info.max_depth} ext_kernel {best.reserved[0]}", flush=True)
+              f"nodes/ray {c.node_visits/c.rays:6.2f} tris/ray {c.tri_tests/c.rays:5.2f} depth {info.max_depth} ext_kernel {best.reserved[0]} build_ms {info.build_ms:.0f} nodes {info.n_nodes}", flush=True)
 r.Dispose()
