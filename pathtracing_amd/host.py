@@ -200,6 +200,21 @@ class Renderer:
         _check(N.lib.pt_framebuffer_read_rgba8(self._ctx, _ptr(out), out.size), self._ctx)
         return out
 
+    def SaveImage(self, path):
+        """Image output — what replaces the reference's window (display path Renderer.cs:1042-1121).
+        `.ppm`: 8-bit, the clamp-and-round R8G8B8A8Unorm image of Renderer.cs:124; `.pfm`: linear float radiance, bottom-up rows."""
+        w, h = self.Params.width, self.Params.height
+        if path.lower().endswith(".pfm"):
+            rgb = np.ascontiguousarray(self.ReadFramebuffer()[::-1, :, :3], "<f4")
+            with open(path, "wb") as f:
+                f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
+                f.write(rgb.tobytes())
+        else:
+            rgb = np.ascontiguousarray(self.ReadFramebufferRGBA8()[..., :3])
+            with open(path, "wb") as f:
+                f.write(b"P6\n%d %d\n255\n" % (w, h))
+                f.write(rgb.tobytes())
+
     def TilesDevice(self):
         """Device view (for torch.as_tensor) of this rank's tile-major radiance sums after a frame."""
         ptr, n = C.c_void_p(), C.c_uint64()

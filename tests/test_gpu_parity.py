@@ -278,6 +278,19 @@ def test_errors_raise_like_the_reference(P, renderer):
     r2.Dispose(); r2.Dispose()                  # idempotent, like Dispose(bool) at Renderer.cs:1192
 
 
+def test_image_output(P, pto, renderer, tmp_path):
+    """PPM carries the reference's R8G8B8A8Unorm quantisation (Renderer.cs:124), PFM the linear floats."""
+    renderer.Params = P.make_params(97, 41, mode=P.native.PT_REFERENCE_SPHERE)
+    renderer.Render(0.0)
+    renderer.SaveImage(str(tmp_path / "f.ppm")); renderer.SaveImage(str(tmp_path / "f.pfm"))
+    of, ob = pto.reference_sphere(97, 41)
+    raw = open(tmp_path / "f.ppm", "rb").read()
+    assert raw.startswith(b"P6\n97 41\n255\n") and np.array_equal(np.frombuffer(raw[len(b"P6\n97 41\n255\n"):], np.uint8).reshape(41, 97, 3), ob[..., :3])
+    raw = open(tmp_path / "f.pfm", "rb").read()
+    hdr = b"PF\n97 41\n-1.0\n"
+    assert raw.startswith(hdr) and np.array_equal(np.frombuffer(raw[len(hdr):], "<f4").reshape(41, 97, 3)[::-1], of[..., :3])
+
+
 def test_app_runs_the_reference_frame(P, pto):
     """Program.cs:3-7 / App.Run (App.cs:15-21): window 1920x1080, renderer, render loop — one frame of the reference kernel."""
     with P.App(frames=2) as app:
