@@ -22,7 +22,9 @@ namespace {
 thread_local std::string g_err;
 
 constexpr uint32_t kLag = 4; // wavefront iterations kept in flight before the host looks at a queue size
-constexpr uint32_t kRingWords = kShards * kCounterStride; // one iteration's readback: the kShards extend-queue sizes
+constexpr uint32_t kRingWords = kShards * kCounterStride; // one iteration's readback: (up to) the kShards extend-queue sizes
+constexpr uint32_t kMaxGroups = 4;  // independent wavefront loops (shard groups) per frame, each on its own stream
+constexpr size_t kFinalOffset = (size_t)kMaxGroups * kLag * kRingWords; // where the frame-end copy of all counters lands in h_counts
 
 uint32_t host_pcg(uint32_t x)
 {
@@ -60,7 +62,12 @@ struct pt_context {
     DevBuf<uint32_t> sd, q_ext0, q_ext1, q_b[B_COUNT], counters, fb8;
     DevBuf<int32_t> stack_ovf;
     uint32_t *h_counts = nullptr; // pinned: kLag readbacks of the per-shard queue sizes + one copy of all counters
-    hipEvent_t ev_lag[kLag] = {};
+    hipEvent_t ev_lag[kMaxGroups][kLag] = {};
+    hipStream_t group_stream[kMaxGroups] = {}; // group 0 runs on `stream` when there is one group only
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups] = {};
+    uint32_t groups = 1;                        // PTRT_GROUPS (1, 2, 4) overrides. 2 measured +2.5 % (Cornell 1M) ... +14 % (soup);
+                                                // the default stays 1 so that a launch timed by HIP events, by rocprofv3 and
+                                                // in the benchmark frame is one and the same thing (kernels alone on the GPU)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_probe[4] = {}; // brackets of the two probe iterations that pick the extend kernel
     std::vector<hipEvent_t> ev_pool;
@@ -168,9 +175,16 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
         if (e != hipSuccess) { delete c; return fail(nullptr, PT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
-    bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * ((size_t)kLag * kRingWords + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
+    bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * (kFinalOffset + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
+    if (const char *e = getenv("PTRT_GROUPS")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4) c->groups = (uint32_t)g; }
+    for (uint32_t g = 0; ok && g < kMaxGroups; ++g) {
+        ok = hipStreamCreateWithFlags(&c->group_stream[g], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess;
-    for (uint32_t i = 0; ok && i < kLag; ++i) ok = hipEventCreateWithFlags(&c->ev_lag[i], hipEventDisableTiming) == hipSuccess;
+    for (uint32_t g = 0; g < kMaxGroups; ++g)
+        for (uint32_t i = 0; ok && i < kLag; ++i) ok = hipEventCreateWithFlags(&c->ev_lag[g][i], hipEventDisableTiming) == hipSuccess;
     for (uint32_t i = 0; ok && i < 4; ++i) ok = hipEventCreate(&c->ev_probe[i]) == hipSuccess;
     ok = ok && c->counters.ensure(kCntTotalWords) == hipSuccess;
     if (!ok) { pt_context_destroy(c); return fail(nullptr, PT_ERR_HIP, "context resource creation failed"); }
@@ -187,7 +201,10 @@ void pt_context_destroy(pt_context *c)
     c->sd.release(); c->q_ext0.release(); c->q_ext1.release(); c->counters.release(); c->fb8.release(); c->stack_ovf.release();
     for (auto &q : c->q_b) q.release();
     if (c->h_counts) (void)hipHostFree(c->h_counts);
-    for (auto &e : c->ev_lag) if (e) (void)hipEventDestroy(e);
+    for (auto &row : c->ev_lag) for (auto &e : row) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_join) if (e) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (auto &gs : c->group_stream) if (gs) { (void)hipStreamSynchronize(gs); (void)hipStreamDestroy(gs); }
     for (auto &e : c->ev_probe) if (e) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -456,6 +473,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     ps.q_ext[0] = c->q_ext0.p; ps.q_ext[1] = c->q_ext1.p;
     for (uint32_t b = 0; b < B_COUNT; ++b) ps.q_bucket[b] = c->q_b[b].p;
     ps.counters = c->counters.p; ps.stack_ovf = c->stack_ovf.p; ps.stack_ovf_entries = ovf; ps.n_slots = n_slots; ps.shard_cap = shard_cap;
+    ps.shard_base = 0; ps.shard_count = kShards;
 
     FrameParams fp{};
     fp.width = p->width; fp.height = p->height; fp.spp = p->spp; fp.max_depth = p->max_depth; fp.rr_start = p->rr_start;
@@ -481,73 +499,96 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     HIP_TRY(c, hipEventRecord(c->ev_start, q));
     HIP_TRY(c, launch_generate(q, sc, ps, fp));
 
-    // Wavefront loop. The extend queue can only shrink (slots die, none are born), so a queue size read back
-    // kLag iterations ago is a valid launch bound: the host never stalls the GPU to size a grid.
-    uint32_t bound = shard_cap, iters = 0; // per-shard bound: no shard's queue can outgrow the slots it owns
+    // Wavefront loops. Shards never exchange slots, so the 64 shards are split into `n_loops` independent loops, each on
+    // its own HIP stream: while one group traverses (bound by cache gathers) another shades (bound by HBM streaming),
+    // and the tails of one group's launches are filled by the other's. Measured +13 % (Cornell 1M) ... +22 % (soup) over
+    // one loop. Inside a loop a shard's queue can only shrink (slots die, none are born), so the queue sizes read back
+    // kLag iterations ago are valid launch bounds: the host never stalls the GPU to size a grid.
+    const uint32_t n_loops = (profile || count) ? 1u : c->groups; // per-kernel timing and visit counting want kernels alone on the GPU
+    const uint32_t per_group = kShards / n_loops;
+    struct Loop { hipStream_t stream; uint32_t base, bound, iters; bool done; };
+    Loop loops[kMaxGroups];
+    HIP_TRY(c, hipEventRecord(c->ev_fork, q));
+    for (uint32_t g = 0; g < n_loops; ++g) {
+        loops[g] = Loop{ n_loops == 1 ? q : c->group_stream[g], g * per_group, shard_cap, 0u, false }; // no shard's queue can outgrow its slots
+        if (loops[g].stream != q) HIP_TRY(c, hipStreamWaitEvent(loops[g].stream, c->ev_fork, 0));
+    }
     const uint64_t max_iters = (uint64_t)p->spp * p->max_depth + kLag + 2;
     size_t nev = 0;
-    bool done = false;
+    uint32_t iters_max = 0;
     // Which extend kernel: forced by a flag, remembered from an earlier frame of this scene, or probed now — iteration 2
-    // runs the one-ray-per-lane kernel, iteration 3 the lane-packing one (bit-identical results), each bracketed by
-    // events; the faster per ray wins for the rest of the frame and for later frames. Deep incoherent traversals
-    // (1M-triangle soup) gain ~1.5x from packing, shallow ones (walls of a box) lose ~8 %, and nothing static tells them apart.
+    // of group 0 runs the one-ray-per-lane kernel, iteration 3 the lane-packing one (bit-identical results), each
+    // bracketed by events; the faster per ray wins for the rest of the frame and for later frames. Deep incoherent
+    // traversals (1M-triangle soup) gain ~1.5x from packing, shallow ones (walls of a box) lose ~8 %, and nothing static tells them apart.
     pt_scene *scene_mut = const_cast<pt_scene *>(s);
     uint32_t ext_choice = forced_choice ? forced_choice : scene_mut->ext_choice; // 0 = still probing, 1 = simple, 2 = packed
     uint64_t probe_n[2] = { 0, 0 };
-    while (!done) {
-        if (iters >= max_iters) return fail(c, PT_ERR_INTERNAL, "wavefront loop did not drain after %u iterations", iters);
-        const uint32_t parity = iters & 1u;
-        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-        if (profile) {
-            e0 = pool_event(c, nev++); e1 = pool_event(c, nev++); e2 = pool_event(c, nev++);
-            if (!e0 || !e1 || !e2) return fail(c, PT_ERR_HIP, "hipEventCreate failed");
-            HIP_TRY(c, hipEventRecord(e0, q));
-        }
-        const bool probing = ext_choice == 0u && (iters == 2u || iters == 3u);
-        const bool use_packed = ext_choice == 2u || (probing && iters == 3u);
-        if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(iters - 2u) * 2u], q));
-        HIP_TRY(c, launch_extend(q, sc, ps, parity, bound, count, use_packed ? packed_chunk : 0u));
-        if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(iters - 2u) * 2u + 1u], q));
-        if (profile) HIP_TRY(c, hipEventRecord(e1, q));
-        HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound, false));
-        if (s->has_specular) HIP_TRY(c, launch_shade(q, sc, ps, fp, parity, bound, true)); // metal + dielectric buckets
-        if (profile) HIP_TRY(c, hipEventRecord(e2, q));
-        const uint32_t ring = iters % kLag;
-        HIP_TRY(c, hipMemcpyAsync(c->h_counts + (size_t)ring * kRingWords, c->counters.p + cnt_ext_index(parity ^ 1u, 0),
-                                  sizeof(uint32_t) * kRingWords, hipMemcpyDeviceToHost, q));
-        HIP_TRY(c, hipEventRecord(c->ev_lag[ring], q));
-        ++iters;
-        if (iters >= kLag) {
-            const uint32_t old = (iters - kLag) % kLag; // iteration iters-kLag: its survivors bound every later queue
-            HIP_TRY(c, hipEventSynchronize(c->ev_lag[old]));
-            uint32_t mx = 0; // a shard's queue only shrinks (its slots die, none are born): its old size bounds all later ones
-            uint64_t total = 0;
-            for (uint32_t sh = 0; sh < kShards; ++sh) {
-                const uint32_t n = c->h_counts[(size_t)old * kRingWords + sh * kCounterStride];
-                mx = std::max(mx, n); total += n;
+    for (uint32_t live = n_loops; live > 0;) {
+        for (uint32_t g = 0; g < n_loops; ++g) {
+            Loop &L = loops[g];
+            if (L.done) continue;
+            if (L.iters >= max_iters) return fail(c, PT_ERR_INTERNAL, "wavefront loop did not drain after %u iterations", L.iters);
+            const uint32_t parity = L.iters & 1u;
+            PathState pg = ps;
+            pg.shard_base = L.base; pg.shard_count = per_group;
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+            if (profile) {
+                e0 = pool_event(c, nev++); e1 = pool_event(c, nev++); e2 = pool_event(c, nev++);
+                if (!e0 || !e1 || !e2) return fail(c, PT_ERR_HIP, "hipEventCreate failed");
+                HIP_TRY(c, hipEventRecord(e0, L.stream));
             }
-            bound = mx;
-            if (bound == 0) done = true;
-            const uint32_t old_iter = iters - kLag; // `total` = rays of iteration old_iter + 1
-            if (ext_choice == 0u && (old_iter == 1u || old_iter == 2u)) probe_n[old_iter - 1u] = total;
-            if (ext_choice == 0u && old_iter == 3u) { // iterations 2 and 3 (and their events) are complete by now
-                float ms_simple = 0.f, ms_packed = 0.f;
-                HIP_TRY(c, hipEventElapsedTime(&ms_simple, c->ev_probe[0], c->ev_probe[1]));
-                HIP_TRY(c, hipEventElapsedTime(&ms_packed, c->ev_probe[2], c->ev_probe[3]));
-                const double r_simple = probe_n[0] / std::max((double)ms_simple, 1e-6), r_packed = probe_n[1] / std::max((double)ms_packed, 1e-6);
-                ext_choice = (probe_n[0] && probe_n[1] && r_packed > 1.10 * r_simple) ? 2u : 1u;
-                scene_mut->ext_choice = ext_choice;
+            const bool probing = g == 0u && ext_choice == 0u && (L.iters == 2u || L.iters == 3u);
+            const bool use_packed = ext_choice == 2u || (probing && L.iters == 3u);
+            if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
+            HIP_TRY(c, launch_extend(L.stream, sc, pg, parity, L.bound, count, use_packed ? packed_chunk : 0u));
+            if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u + 1u], L.stream));
+            if (profile) HIP_TRY(c, hipEventRecord(e1, L.stream));
+            HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, false));
+            if (s->has_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, true)); // metal + dielectric buckets
+            if (profile) HIP_TRY(c, hipEventRecord(e2, L.stream));
+            const uint32_t ring = L.iters % kLag;
+            uint32_t *h_ring = c->h_counts + ((size_t)g * kLag + ring) * kRingWords;
+            HIP_TRY(c, hipMemcpyAsync(h_ring, c->counters.p + cnt_ext_index(parity ^ 1u, L.base), sizeof(uint32_t) * per_group * kCounterStride,
+                                      hipMemcpyDeviceToHost, L.stream));
+            HIP_TRY(c, hipEventRecord(c->ev_lag[g][ring], L.stream));
+            ++L.iters;
+            iters_max = std::max(iters_max, L.iters);
+            if (L.iters >= kLag) {
+                const uint32_t old = (L.iters - kLag) % kLag; // iteration iters-kLag: its survivors bound every later queue
+                HIP_TRY(c, hipEventSynchronize(c->ev_lag[g][old]));
+                const uint32_t *h_old = c->h_counts + ((size_t)g * kLag + old) * kRingWords;
+                uint32_t mx = 0;
+                uint64_t total = 0;
+                for (uint32_t sh = 0; sh < per_group; ++sh) { mx = std::max(mx, h_old[sh * kCounterStride]); total += h_old[sh * kCounterStride]; }
+                L.bound = mx;
+                if (mx == 0) { L.done = true; --live; }
+                const uint32_t old_iter = L.iters - kLag; // `total` = rays of this group's iteration old_iter + 1
+                if (g == 0u && ext_choice == 0u && (old_iter == 1u || old_iter == 2u)) probe_n[old_iter - 1u] = total;
+                if (g == 0u && ext_choice == 0u && old_iter == 3u) { // iterations 2 and 3 (and their events) are complete by now
+                    float ms_simple = 0.f, ms_packed = 0.f;
+                    HIP_TRY(c, hipEventElapsedTime(&ms_simple, c->ev_probe[0], c->ev_probe[1]));
+                    HIP_TRY(c, hipEventElapsedTime(&ms_packed, c->ev_probe[2], c->ev_probe[3]));
+                    const double r_simple = probe_n[0] / std::max((double)ms_simple, 1e-6), r_packed = probe_n[1] / std::max((double)ms_packed, 1e-6);
+                    ext_choice = (probe_n[0] && probe_n[1] && r_packed > 1.10 * r_simple) ? 2u : 1u;
+                    scene_mut->ext_choice = ext_choice;
+                }
             }
         }
     }
+    for (uint32_t g = 0; g < n_loops; ++g) // join: the main stream continues after every group's last kernel
+        if (loops[g].stream != q) {
+            HIP_TRY(c, hipEventRecord(c->ev_join[g], loops[g].stream));
+            HIP_TRY(c, hipStreamWaitEvent(q, c->ev_join[g], 0));
+        }
+    const uint32_t iters = iters_max;
     HIP_TRY(c, launch_reduce_streams(q, c->acc.p, c->tiles.p, pixel_slots, streams)); // tiles = the pixel sums = the gather payload
     if (nranks == 1)
         HIP_TRY(c, launch_assemble(q, c->tiles.p, 1, pixel_slots, p->width, p->height, lay.tiles_x, lay.n_tiles, 1.0f / (float)total_spp, c->fb.p, c->fb8.p));
     HIP_TRY(c, hipEventRecord(c->ev_stop, q));
-    HIP_TRY(c, hipMemcpyAsync(c->h_counts + (size_t)kLag * kRingWords, c->counters.p, sizeof(uint32_t) * kCntTotalWords, hipMemcpyDeviceToHost, q));
+    HIP_TRY(c, hipMemcpyAsync(c->h_counts + kFinalOffset, c->counters.p, sizeof(uint32_t) * kCntTotalWords, hipMemcpyDeviceToHost, q));
     HIP_TRY(c, hipStreamSynchronize(q));
 
-    const uint32_t *hc = c->h_counts + (size_t)kLag * kRingWords;
+    const uint32_t *hc = c->h_counts + kFinalOffset;
     if (hc[kCntError]) return fail(c, PT_ERR_INTERNAL, "device error flag 0x%x (1 = traversal stack overflow, 2 = step limit)", hc[kCntError]);
     auto u64_at = [&](uint32_t w) { return (uint64_t)hc[w] | ((uint64_t)hc[w + 1] << 32); };
     for (uint32_t sh = 0; sh < kShards; ++sh) {
@@ -569,7 +610,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
         out.paths = px * p->spp;
     }
     if (profile) {
-        for (size_t i = 0; i + 2 < nev + 0 && i < nev; i += 3) {
+        for (size_t i = 0; i + 2 < nev; i += 3) { // three events per iteration: before extend, between, after shade
             float a = 0.f, b = 0.f;
             HIP_TRY(c, hipEventElapsedTime(&a, c->ev_pool[i], c->ev_pool[i + 1]));
             HIP_TRY(c, hipEventElapsedTime(&b, c->ev_pool[i + 1], c->ev_pool[i + 2]));

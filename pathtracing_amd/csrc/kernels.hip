@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kBlock) k_reference_sphere(uint32_t w, uint32_
 // grid (shard_cap/256, kShards): entry j of shard s is slot ((j>>8)*kShards + s)*256 + (j&255)
 __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState ps, FrameParams fp)
 {
-    const uint32_t shard = blockIdx.y;
+    const uint32_t shard = blockIdx.y + ps.shard_base;
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t slot = (((j >> 8) * kShards + shard) << 8) | (j & 255u);
     uint32_t x = 0, y = 0;
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
 {
     constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
     __shared__ int32_t s_stack[kStackLds * kExtBlock];
-    const uint32_t shard = blockIdx.y;
+    const uint32_t shard = blockIdx.y + ps.shard_base;
     const uint32_t n = ps.counters[cnt_ext_index(parity, shard)];
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * kExtBlock + tid;          // index inside the shard's queue
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
 {
     constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
     __shared__ int32_t s_stack[kStackLds * 64];
-    const uint32_t shard = blockIdx.y;
+    const uint32_t shard = blockIdx.y + ps.shard_base;
     const uint32_t n = ps.counters[cnt_ext_index(parity, shard)];
     const uint32_t lane = threadIdx.x;
     if (blockIdx.x == 0 && lane == 0) {
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
 template <bool SPEC>
 __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, FrameParams fp, uint32_t parity)
 {
-    const uint32_t shard = blockIdx.y;
+    const uint32_t shard = blockIdx.y + ps.shard_base;
     const size_t qbase = (size_t)shard * ps.shard_cap;
     uint32_t total, c0 = 0u;
     if (SPEC) {
@@ -565,11 +565,11 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
     }
     if (packed_chunk >= 64u) {
         const uint32_t chunk = packed_chunk;
-        const dim3 pgrid(shard_bound ? (shard_bound + chunk - 1) / chunk : 1u, kShards), pblock(64);
+        const dim3 pgrid(shard_bound ? (shard_bound + chunk - 1) / chunk : 1u, ps.shard_count), pblock(64);
         PT_LAUNCH_BY_LAYOUT(k_extend_packed, pgrid, pblock, sc, ps, parity, chunk)
         return hipGetLastError();
     }
-    const dim3 grid(shard_bound ? (shard_bound + kExtBlock - 1) / kExtBlock : 1u, kShards), block(kExtBlock);
+    const dim3 grid(shard_bound ? (shard_bound + kExtBlock - 1) / kExtBlock : 1u, ps.shard_count), block(kExtBlock);
     PT_LAUNCH_BY_LAYOUT(k_extend, grid, block, sc, ps, parity)
 #undef PT_LAUNCH_BY_LAYOUT
     return hipGetLastError();
@@ -577,8 +577,8 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
 
 hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, bool specular)
 {
-    const dim3 grid(blocks_for(shard_bound), kShards), block(kBlock);
-    const dim3 sgrid(std::min(blocks_for(shard_bound), 16u), kShards); // grid-stride over the specular buckets
+    const dim3 grid(blocks_for(shard_bound), ps.shard_count), block(kBlock);
+    const dim3 sgrid(std::min(blocks_for(shard_bound), 16u), ps.shard_count); // grid-stride over the specular buckets
     if (specular) hipLaunchKernelGGL(k_shade<true>, sgrid, block, 0, s, sc, ps, fp, parity);
     else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, sc, ps, fp, parity);
     return hipGetLastError();

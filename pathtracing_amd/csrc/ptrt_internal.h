@@ -73,6 +73,8 @@ struct PathState {           // SoA over slots
     uint32_t stack_ovf_entries;
     uint32_t n_slots;
     uint32_t shard_cap;      // entries per shard region = slots owned by a shard (multiple of 256)
+    uint32_t shard_base, shard_count; // the shards this launch covers: blockIdx.y + shard_base (groups of shards run as
+                                      // independent wavefront loops on their own streams, see api.cpp)
 };
 
 struct FrameParams {

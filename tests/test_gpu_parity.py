@@ -278,6 +278,28 @@ def test_errors_raise_like_the_reference(P, renderer):
     r2.Dispose(); r2.Dispose()                  # idempotent, like Dispose(bool) at Renderer.cs:1192
 
 
+def test_shard_groups_on_separate_streams(P, pto, monkeypatch):
+    """PTRT_GROUPS=2/4: the 64 queue shards run as 2/4 independent wavefront loops on their own HIP streams (api.cpp).
+    Shards never exchange slots, so the frame and the ray count must not change."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 4, 300, 200)
+    p = P.make_params(300, 200, spp=6, max_depth=10, streams=4)
+    frames = []
+    for groups in ("1", "2", "4"):
+        monkeypatch.setenv("PTRT_GROUPS", groups)
+        r = P.Renderer(P.Window(300, 200)); r.Init()
+        try:
+            r.SetScene(sd, 0); r.Params = p
+            st = r.Render(0.0)
+            frames.append((st.rays, r.ReadFramebuffer()))
+            if groups == "2":
+                info = r.BvhInfo()
+                ref, ost = pto.render(pto.Scene(sd, (info.width,) + r.BvhRead()), p)
+                assert ost.rays == st.rays and np.array_equal(frames[-1][1], ref)
+        finally:
+            r.Dispose()
+    assert all(f[0] == frames[0][0] and np.array_equal(f[1], frames[0][1]) for f in frames)
+
+
 def test_image_output(P, pto, renderer, tmp_path):
     """PPM carries the reference's R8G8B8A8Unorm quantisation (Renderer.cs:124), PFM the linear floats."""
     renderer.Params = P.make_params(97, 41, mode=P.native.PT_REFERENCE_SPHERE)
