@@ -424,7 +424,8 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     static const uint32_t chunk_env = [] { const char *e = getenv("PTRT_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }(); // tuning aid
     // rays per wavefront of the lane-packing kernel: 256 once several sample streams keep the queues long, else 128 (measured)
     const uint32_t packed_chunk = chunk_env >= 64u ? chunk_env : ((p->streams >= 4u) ? 256u : 128u);
-    const uint32_t forced_choice = (p->flags & PT_FLAG_EXTEND_PACKED) ? 2u : (p->flags & PT_FLAG_EXTEND_SIMPLE) ? 1u : 0u;
+    const bool bucket_specular = (p->flags & PT_FLAG_BUCKET_SPECULAR) != 0;
+    const uint32_t forced_choice =(p->flags & PT_FLAG_EXTEND_PACKED) ? 2u : (p->flags & PT_FLAG_EXTEND_SIMPLE) ? 1u : 0u;
 
     if (p->mode == PT_REFERENCE_SPHERE) {
         // Renderer.ComputeFrame: one dispatch, then the host blocks on the fence (Renderer.cs:1020,1036,972)
@@ -543,8 +544,12 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             HIP_TRY(c, launch_extend(L.stream, sc, pg, parity, L.bound, count, use_packed ? packed_chunk : 0u));
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u + 1u], L.stream));
             if (profile) HIP_TRY(c, hipEventRecord(e1, L.stream));
-            HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, false));
-            if (s->has_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, true)); // metal + dielectric buckets
+            if (!s->has_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 0));      // Lambert only: lean kernel
+            else if (!bucket_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 2)); // all kinds in queue order
+            else {
+                HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 0));
+                HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 1)); // metal + dielectric buckets
+            }
             if (profile) HIP_TRY(c, hipEventRecord(e2, L.stream));
             const uint32_t ring = L.iters % kLag;
             uint32_t *h_ring = c->h_counts + ((size_t)g * kLag + ring) * kRingWords;

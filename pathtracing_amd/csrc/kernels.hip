@@ -365,14 +365,20 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shade<false>: walks the extend queue of this iteration in the SAME order k_extend did, so ray/throughput/hit
-//                 reads are the coalesced, L2-warm lines k_extend just touched. Misses and Lambert hits are shaded
-//                 in place; the rare specular kinds (metal, dielectric) are deferred to per-kind bucket queues so that
-//                 their long BSDF code never runs in a wave of diffuse lanes.
-// k_shade<true> : walks the two specular buckets, concatenated, so the kind switch is wave-uniform.
-template <bool SPEC>
+// k_shade<SHADE_QUEUE>   : walks the extend queue of this iteration in the SAME order k_extend did, so ray/throughput/hit
+//                          reads are the coalesced, L2-warm lines k_extend just touched. Misses and Lambert hits are shaded
+//                          in place; specular kinds (metal, dielectric) are deferred to per-kind bucket queues.
+// k_shade<SHADE_BUCKETS> : walks the two specular buckets, concatenated, so the kind switch is wave-uniform.
+// k_shade<SHADE_INLINE>  : like SHADE_QUEUE but shades the specular kinds in place too (a divergent branch). Default for scenes
+//                          with specular materials: deferring re-appends those slots at the end of the next queue, which
+//                          scrambles the queue's slot order a little more every iteration; measured on Cornell + glass + metal,
+//                          the same 16.6 M-ray launch went from 0.78 ms to 2.15 ms (shade) and 0.32 to 0.74 ms (extend) within
+//                          30 iterations as slot-indexed state lost its coalescing. Order beats divergence here.
+enum ShadeMode { SHADE_QUEUE = 0, SHADE_BUCKETS = 1, SHADE_INLINE = 2 };
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, FrameParams fp, uint32_t parity)
 {
+    constexpr bool SPEC = MODE == SHADE_BUCKETS;
     const uint32_t shard = blockIdx.y + ps.shard_base;
     const size_t qbase = (size_t)shard * ps.shard_cap;
     uint32_t total, c0 = 0u;
@@ -433,7 +439,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
             const float4 m0 = sc.mats[(size_t)mat * 3], m1 = sc.mats[(size_t)mat * 3 + 1], m2 = sc.mats[(size_t)mat * 3 + 2];
             const V3 alb = v3(m0.y, m0.z, m0.w), emi = xyz(m1);
             const uint32_t kind = __float_as_uint(m0.x);
-            if (!SPEC && kind != (uint32_t)PT_LAMBERT) defer = 1u + kind; // shaded by k_shade<true>; this lane leaves everything untouched
+            if (MODE == SHADE_QUEUE && kind != (uint32_t)PT_LAMBERT) defer = 1u + kind; // shaded by k_shade<SHADE_BUCKETS>; this lane leaves everything untouched
             else {
             if (emi.x != 0.0f || emi.y != 0.0f || emi.z != 0.0f) add(emi);
             if (depth >= fp.max_depth) term = true;
@@ -442,8 +448,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
                 V3 wi = d, W = v3(1.f, 1.f, 1.f);
                 float side = 1.0f;
                 bool ok = true;
-                if (!SPEC) sample_lambert(alb, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
-                else if (b == B_METAL) ok = sample_metal(alb, m1.w, d, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
+                const uint32_t bk = MODE == SHADE_QUEUE ? (uint32_t)B_LAMBERT : MODE == SHADE_BUCKETS ? b : 1u + kind;
+                if (bk == B_LAMBERT) sample_lambert(alb, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
+                else if (bk == B_METAL) ok = sample_metal(alb, m1.w, d, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
                 else sample_dielectric(alb, m2.x, d, n, front, u01(key, 6u + 4u * bb), wi, W, side);
                 if (!ok) term = true;
                 else {
@@ -486,7 +493,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
         }
     }
     wave_push(&ps.counters[cnt_ext_index(parity ^ 1u, shard)], ps.q_ext[parity ^ 1u] + qbase, alive, slot);
-    if (!SPEC) {
+    if (MODE == SHADE_QUEUE) {
         wave_push(&ps.counters[cnt_bucket_index(parity, B_METAL, shard)], ps.q_bucket[B_METAL] + qbase, defer == B_METAL, slot);
         wave_push(&ps.counters[cnt_bucket_index(parity, B_DIELECTRIC, shard)], ps.q_bucket[B_DIELECTRIC] + qbase, defer == B_DIELECTRIC, slot);
     }
@@ -575,12 +582,13 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
     return hipGetLastError();
 }
 
-hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, bool specular)
+hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, int mode)
 {
     const dim3 grid(blocks_for(shard_bound), ps.shard_count), block(kBlock);
     const dim3 sgrid(std::min(blocks_for(shard_bound), 16u), ps.shard_count); // grid-stride over the specular buckets
-    if (specular) hipLaunchKernelGGL(k_shade<true>, sgrid, block, 0, s, sc, ps, fp, parity);
-    else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, sc, ps, fp, parity);
+    if (mode == SHADE_BUCKETS) hipLaunchKernelGGL(k_shade<SHADE_BUCKETS>, sgrid, block, 0, s, sc, ps, fp, parity);
+    else if (mode == SHADE_INLINE) hipLaunchKernelGGL(k_shade<SHADE_INLINE>, grid, block, 0, s, sc, ps, fp, parity);
+    else hipLaunchKernelGGL(k_shade<SHADE_QUEUE>, grid, block, 0, s, sc, ps, fp, parity);
     return hipGetLastError();
 }
 

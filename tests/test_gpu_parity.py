@@ -278,6 +278,17 @@ def test_errors_raise_like_the_reference(P, renderer):
     r2.Dispose(); r2.Dispose()                  # idempotent, like Dispose(bool) at Renderer.cs:1192
 
 
+def test_bucketed_specular_shading_is_identical(P, pto, renderer):
+    """PT_FLAG_BUCKET_SPECULAR: metal / dielectric hits shaded from per-kind bucket queues instead of in queue order.
+    A scheduling choice only — frame, ray count and visit counters must equal the oracle's either way."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 21, 180, 120)
+    for flags in (0, P.native.PT_FLAG_BUCKET_SPECULAR):
+        p = P.make_params(180, 120, spp=6, max_depth=16, streams=2, flags=flags)
+        img, st, ref, ost = run_both(P, pto, renderer, sd, p, 0, count=True)
+        assert_parity(img, st, ref, ost)
+        assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests)
+
+
 def test_shard_groups_on_separate_streams(P, pto, monkeypatch):
     """PTRT_GROUPS=2/4: the 64 queue shards run as 2/4 independent wavefront loops on their own HIP streams (api.cpp).
     Shards never exchange slots, so the frame and the ray count must not change."""
