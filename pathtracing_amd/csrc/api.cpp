@@ -68,6 +68,8 @@ struct pt_context {
     uint32_t groups = 1;                        // PTRT_GROUPS (1, 2, 4) overrides. 2 measured +2.5 % (Cornell 1M) ... +14 % (soup);
                                                 // the default stays 1 so that a launch timed by HIP events, by rocprofv3 and
                                                 // in the benchmark frame is one and the same thing (kernels alone on the GPU)
+    double compact_below = 0.75;                // PTRT_COMPACT overrides: k_shade re-packs a loop's queues once alive/length drops
+                                                // below this (>1 = every iteration, 0 = never); otherwise queues are carried in place
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_probe[4] = {}; // brackets of the two probe iterations that pick the extend kernel
     std::vector<hipEvent_t> ev_pool;
@@ -177,6 +179,7 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
     }
     bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * (kFinalOffset + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
     if (const char *e = getenv("PTRT_GROUPS")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4) c->groups = (uint32_t)g; }
+    if (const char *e = getenv("PTRT_COMPACT")) { const double v = atof(e); if (v >= 0.0 && v <= 2.0) c->compact_below = v; }
     for (uint32_t g = 0; ok && g < kMaxGroups; ++g) {
         ok = hipStreamCreateWithFlags(&c->group_stream[g], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) == hipSuccess;
@@ -507,11 +510,16 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     // kLag iterations ago are valid launch bounds: the host never stalls the GPU to size a grid.
     const uint32_t n_loops = (profile || count) ? 1u : c->groups; // per-kernel timing and visit counting want kernels alone on the GPU
     const uint32_t per_group = kShards / n_loops;
-    struct Loop { hipStream_t stream; uint32_t base, bound, iters; bool done; };
+    //
+    // Queues are carried over IN PLACE from one iteration to the next (k_shade, compact = 0): a lane writes its own queue
+    // position, dead paths leave holes, and lane <-> slot stays the generation order, so the slot-indexed state keeps
+    // its coalescing and k_shade needs no returning atomic. Only when the lagged alive/length ratio of a loop falls
+    // below `compact_below` does one k_shade re-pack the survivors (ballot + atomic append), which shortens the launches.
+    struct Loop { hipStream_t stream; uint32_t base, bound, iters; bool done, compact_next; int64_t last_compact; };
     Loop loops[kMaxGroups];
     HIP_TRY(c, hipEventRecord(c->ev_fork, q));
     for (uint32_t g = 0; g < n_loops; ++g) {
-        loops[g] = Loop{ n_loops == 1 ? q : c->group_stream[g], g * per_group, shard_cap, 0u, false }; // no shard's queue can outgrow its slots
+        loops[g] = Loop{ n_loops == 1 ? q : c->group_stream[g], g * per_group, shard_cap, 0u, false, false, -1 }; // no shard's queue can outgrow its slots
         if (loops[g].stream != q) HIP_TRY(c, hipStreamWaitEvent(loops[g].stream, c->ev_fork, 0));
     }
     const uint64_t max_iters = (uint64_t)p->spp * p->max_depth + kLag + 2;
@@ -523,7 +531,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     // traversals (1M-triangle soup) gain ~1.5x from packing, shallow ones (walls of a box) lose ~8 %, and nothing static tells them apart.
     pt_scene *scene_mut = const_cast<pt_scene *>(s);
     uint32_t ext_choice = forced_choice ? forced_choice : scene_mut->ext_choice; // 0 = still probing, 1 = simple, 2 = packed
-    uint64_t probe_n[2] = { 0, 0 };
+    uint64_t probe_n[2] = { 0, 0 }, n_compactions = 0;
     for (uint32_t live = n_loops; live > 0;) {
         for (uint32_t g = 0; g < n_loops; ++g) {
             Loop &L = loops[g];
@@ -544,11 +552,13 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             HIP_TRY(c, launch_extend(L.stream, sc, pg, parity, L.bound, count, use_packed ? packed_chunk : 0u));
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u + 1u], L.stream));
             if (profile) HIP_TRY(c, hipEventRecord(e1, L.stream));
-            if (!s->has_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 0));      // Lambert only: lean kernel
-            else if (!bucket_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 2)); // all kinds in queue order
+            const bool compact = L.compact_next || c->compact_below > 1.0 || (bucket_specular && s->has_specular); // buckets re-append: no fixed positions
+            if (compact) { L.compact_next = false; L.last_compact = (int64_t)L.iters; ++n_compactions; }
+            if (!s->has_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 0, compact));      // Lambert only: lean kernel
+            else if (!bucket_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 2, compact)); // all kinds in queue order
             else {
-                HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 0));
-                HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 1)); // metal + dielectric buckets
+                HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 0, true));
+                HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 1, true)); // metal + dielectric buckets
             }
             if (profile) HIP_TRY(c, hipEventRecord(e2, L.stream));
             const uint32_t ring = L.iters % kLag;
@@ -563,11 +573,17 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
                 HIP_TRY(c, hipEventSynchronize(c->ev_lag[g][old]));
                 const uint32_t *h_old = c->h_counts + ((size_t)g * kLag + old) * kRingWords;
                 uint32_t mx = 0;
-                uint64_t total = 0;
-                for (uint32_t sh = 0; sh < per_group; ++sh) { mx = std::max(mx, h_old[sh * kCounterStride]); total += h_old[sh * kCounterStride]; }
+                uint64_t total = 0, len_sum = 0; // word 0 of a shard's line = queue length (holes included), word 1 = alive entries
+                for (uint32_t sh = 0; sh < per_group; ++sh) {
+                    mx = std::max(mx, h_old[sh * kCounterStride]);
+                    len_sum += h_old[sh * kCounterStride];
+                    total += h_old[sh * kCounterStride + 1];
+                }
                 L.bound = mx;
-                if (mx == 0) { L.done = true; --live; }
+                if (total == 0) { L.done = true; --live; }
                 const uint32_t old_iter = L.iters - kLag; // `total` = rays of this group's iteration old_iter + 1
+                // lengths only change when k_shade compacts, so a ratio read after the last compaction is still current
+                if ((int64_t)old_iter >= L.last_compact && (double)total < c->compact_below * (double)len_sum) L.compact_next = true;
                 if (g == 0u && ext_choice == 0u && (old_iter == 1u || old_iter == 2u)) probe_n[old_iter - 1u] = total;
                 if (g == 0u && ext_choice == 0u && old_iter == 3u) { // iterations 2 and 3 (and their events) are complete by now
                     float ms_simple = 0.f, ms_packed = 0.f;
@@ -597,7 +613,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     if (hc[kCntError]) return fail(c, PT_ERR_INTERNAL, "device error flag 0x%x (1 = traversal stack overflow, 2 = step limit)", hc[kCntError]);
     auto u64_at = [&](uint32_t w) { return (uint64_t)hc[w] | ((uint64_t)hc[w + 1] << 32); };
     for (uint32_t sh = 0; sh < kShards; ++sh) {
-        if (hc[cnt_ext_index(0, sh)] || hc[cnt_ext_index(1, sh)]) return fail(c, PT_ERR_INTERNAL, "extend queue of shard %u not empty at frame end", sh);
+        if (hc[cnt_alive_index(0, sh)] || hc[cnt_alive_index(1, sh)]) return fail(c, PT_ERR_INTERNAL, "extend queue of shard %u not empty at frame end", sh);
         out.rays += u64_at(cnt_rays_index(sh));
     }
     float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
@@ -605,6 +621,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     out.node_visits = u64_at(kCntNodes); out.tri_tests = u64_at(kCntTris); out.sphere_tests = u64_at(kCntSph);
     out.iterations = iters; out.extend_launches = iters;
     out.reserved[0] = ext_choice; // extend kernel in use at frame end: 1 = one ray per lane, 2 = lane-packing, 0 = frame too short to probe
+    out.reserved[1] = n_compactions; // k_shade launches that re-packed their queues (the others carried them over in place)
     {   // paths = owned in-image pixels x spp
         uint64_t px = 0;
         for (uint32_t t = p->rank; t < lay.n_tiles; t += nranks) {

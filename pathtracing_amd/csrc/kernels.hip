@@ -100,7 +100,13 @@ __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState p
         ps.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(key));
         ps.sd[slot] = first << 8;
     }
-    wave_push(&ps.counters[cnt_ext_index(0, shard)], ps.q_ext[0] + (size_t)shard * ps.shard_cap, valid, slot);
+    // the first queue is the shard's slots in slot order, holes (off-image pixels, streams with no sample) included
+    if (j < ps.shard_cap) ps.q_ext[0][(size_t)shard * ps.shard_cap + j] = valid ? slot : kInvalidSlot;
+    const uint32_t n_alive = (uint32_t)__syncthreads_count(valid);
+    if (threadIdx.x == 0) {
+        if (n_alive) atomicAdd(&ps.counters[cnt_alive_index(0, shard)], n_alive);
+        if (blockIdx.x == 0) ps.counters[cnt_ext_index(0, shard)] = ps.shard_cap;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -171,13 +177,14 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
     const uint32_t gid = blockIdx.x * kExtBlock + tid;          // index inside the shard's queue
     if (gid == 0) {
         ps.counters[cnt_ext_index(parity ^ 1u, shard)] = 0u;   // next iteration's queue: filled by k_shade after us
+        ps.counters[cnt_alive_index(parity ^ 1u, shard)] = 0u;
         unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
-        *rays += n;                                            // only this thread ever touches rays[shard]
+        *rays += ps.counters[cnt_alive_index(parity, shard)];  // only this thread ever touches rays[shard]
     }
     if (blockIdx.x * kExtBlock >= n) return;
-    const bool active = gid < n;
     const size_t qbase = (size_t)shard * ps.shard_cap;
-    const uint32_t slot = active ? ps.q_ext[parity][qbase + gid] : 0u;
+    const uint32_t slot = gid < n ? ps.q_ext[parity][qbase + gid] : kInvalidSlot;
+    const bool active = slot != kInvalidSlot;                  // holes: paths that ended since the queue was last compacted
     const size_t uid = qbase + gid;                            // unique per thread of this launch
 
     Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
@@ -266,10 +273,11 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
     const uint32_t lane = threadIdx.x;
     if (blockIdx.x == 0 && lane == 0) {
         ps.counters[cnt_ext_index(parity ^ 1u, shard)] = 0u;
+        ps.counters[cnt_alive_index(parity ^ 1u, shard)] = 0u;
         unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
-        *rays += n;
+        *rays += ps.counters[cnt_alive_index(parity, shard)];
     }
-    uint32_t next = blockIdx.x * chunk;                        // wave-uniform cursor into the shard's queue
+    uint32_t next = blockIdx.x * chunk;                       // wave-uniform cursor into the shard's queue
     if (next >= n) return;
     const uint32_t end = min(n, next + chunk);
     const size_t qbase = (size_t)shard * ps.shard_cap;
@@ -312,8 +320,8 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
         const uint32_t avail = end - next;
         if (idle && avail) {
             const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            if (!has && prefix < avail) {
-                slot = queue[next + prefix];
+            if (!has && prefix < avail) slot = queue[next + prefix];
+            if (!has && prefix < avail && slot != kInvalidSlot) { // a hole leaves the lane idle until the next refill
                 const float4 O = ps.ray_o[slot], D = ps.ray_d[slot];
                 o = xyz(O); d = xyz(D);
                 h = Hit{ __builtin_inff(), PT_MISS, PT_MISS };
@@ -328,7 +336,10 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
             }
             next += min((uint32_t)__popcll(idle), avail);
         }
-        if (!__ballot(has)) break;
+        if (!__ballot(has)) {
+            if (next < end) continue; // everything pulled was a hole
+            break;
+        }
         // ---- traverse until enough lanes went idle to make a refill worth its latency (or nothing is left to pull)
         const uint32_t want = (next < end) ? kRefillIdle : 64u;
         for (;;) {
@@ -376,7 +387,7 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
 //                          30 iterations as slot-indexed state lost its coalescing. Order beats divergence here.
 enum ShadeMode { SHADE_QUEUE = 0, SHADE_BUCKETS = 1, SHADE_INLINE = 2 };
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, FrameParams fp, uint32_t parity)
+__global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, FrameParams fp, uint32_t parity, uint32_t compact)
 {
     constexpr bool SPEC = MODE == SHADE_BUCKETS;
     const uint32_t shard = blockIdx.y + ps.shard_base;
@@ -392,12 +403,12 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
     // costs a few hundred trivial blocks instead of one per 256 queue slots. !SPEC: exactly one pass, grid sized by the host.
     for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
     const uint32_t gid = base + threadIdx.x;
-    const bool active = gid < total;
-    uint32_t b = B_LAMBERT, slot = 0u;
+    uint32_t b = B_LAMBERT, slot = kInvalidSlot;
     if (SPEC) {
         b = gid >= c0 ? B_DIELECTRIC : B_METAL;
-        if (active) slot = ps.q_bucket[b][qbase + (gid >= c0 ? gid - c0 : gid)];
-    } else if (active) slot = ps.q_ext[parity][qbase + gid];
+        if (gid < total) slot = ps.q_bucket[b][qbase + (gid >= c0 ? gid - c0 : gid)];
+    } else if (gid < total) slot = ps.q_ext[parity][qbase + gid];
+    const bool active = slot != kInvalidSlot;
     bool alive = false;
     uint32_t defer = 0u; // SPEC == false: bucket this lane's hit must be shaded in (0 = handled here)
 
@@ -492,7 +503,20 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
             ps.sd[slot] = (sample << 8) | depth;
         }
     }
-    wave_push(&ps.counters[cnt_ext_index(parity ^ 1u, shard)], ps.q_ext[parity ^ 1u] + qbase, alive, slot);
+    if (SPEC || compact) {
+        wave_push(&ps.counters[cnt_ext_index(parity ^ 1u, shard)], ps.q_ext[parity ^ 1u] + qbase, alive, slot);
+        const uint64_t m = __ballot(alive);
+        if (m && (lane_id() == 0u)) atomicAdd(&ps.counters[cnt_alive_index(parity ^ 1u, shard)], (uint32_t)__popcll(m));
+    } else {
+        // carry the queue over in place: position gid keeps its slot for as long as the path lives. No returning atomic,
+        // and lane <-> slot stays the generation order (8x8 pixel blocks of one stream per wavefront) for the whole frame.
+        if (gid < total) ps.q_ext[parity ^ 1u][qbase + gid] = alive ? slot : kInvalidSlot;
+        const uint32_t n_alive = (uint32_t)__syncthreads_count(alive);
+        if (threadIdx.x == 0) {
+            if (n_alive) atomicAdd(&ps.counters[cnt_alive_index(parity ^ 1u, shard)], n_alive);
+            if (blockIdx.x == 0) ps.counters[cnt_ext_index(parity ^ 1u, shard)] = total;
+        }
+    }
     if (MODE == SHADE_QUEUE) {
         wave_push(&ps.counters[cnt_bucket_index(parity, B_METAL, shard)], ps.q_bucket[B_METAL] + qbase, defer == B_METAL, slot);
         wave_push(&ps.counters[cnt_bucket_index(parity, B_DIELECTRIC, shard)], ps.q_bucket[B_DIELECTRIC] + qbase, defer == B_DIELECTRIC, slot);
@@ -582,13 +606,14 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
     return hipGetLastError();
 }
 
-hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, int mode)
+hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, int mode, bool compact)
 {
     const dim3 grid(blocks_for(shard_bound), ps.shard_count), block(kBlock);
     const dim3 sgrid(std::min(blocks_for(shard_bound), 16u), ps.shard_count); // grid-stride over the specular buckets
-    if (mode == SHADE_BUCKETS) hipLaunchKernelGGL(k_shade<SHADE_BUCKETS>, sgrid, block, 0, s, sc, ps, fp, parity);
-    else if (mode == SHADE_INLINE) hipLaunchKernelGGL(k_shade<SHADE_INLINE>, grid, block, 0, s, sc, ps, fp, parity);
-    else hipLaunchKernelGGL(k_shade<SHADE_QUEUE>, grid, block, 0, s, sc, ps, fp, parity);
+    const uint32_t cm = compact ? 1u : 0u;
+    if (mode == SHADE_BUCKETS) hipLaunchKernelGGL(k_shade<SHADE_BUCKETS>, sgrid, block, 0, s, sc, ps, fp, parity, 1u);
+    else if (mode == SHADE_INLINE) hipLaunchKernelGGL(k_shade<SHADE_INLINE>, grid, block, 0, s, sc, ps, fp, parity, cm);
+    else hipLaunchKernelGGL(k_shade<SHADE_QUEUE>, grid, block, 0, s, sc, ps, fp, parity, cm);
     return hipGetLastError();
 }
 

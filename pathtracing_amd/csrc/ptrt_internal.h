@@ -39,7 +39,11 @@ constexpr uint32_t kCntError = kCntGlobals + 0;
 constexpr uint32_t kCntNodes = kCntGlobals + 2, kCntTris = kCntGlobals + 4, kCntSph = kCntGlobals + 6; // u64 each
 constexpr uint32_t kCntTotalWords = kCntGlobals + 16;
 
+// An extend queue has LEN entries of which ALIVE hold a slot; the rest are kInvalidSlot holes left by paths that ended
+// while the queue was carried over in place (k_shade, compact == 0). Both counts share the shard's 64-B line.
+constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
 inline __host__ __device__ uint32_t cnt_ext_index(uint32_t parity, uint32_t shard) { return kCntExt + (parity * kShards + shard) * kCounterStride; }
+inline __host__ __device__ uint32_t cnt_alive_index(uint32_t parity, uint32_t shard) { return cnt_ext_index(parity, shard) + 1u; }
 inline __host__ __device__ uint32_t cnt_bucket_index(uint32_t parity, uint32_t bucket, uint32_t shard)
 {
     return kCntBucket + ((parity * B_COUNT + bucket) * kShards + shard) * kCounterStride;
@@ -92,7 +96,10 @@ hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4
 hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp);
 hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count, uint32_t packed_chunk);
 // mode: 0 = queue order, specular kinds deferred to buckets; 1 = the specular buckets; 2 = queue order, everything shaded in place
-hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, int mode);
+// compact: 1 = survivors are appended densely to the next queue (ballot + one returning atomic per wavefront);
+//          0 = every lane writes its own position of the next queue (slot or kInvalidSlot): no returning atomics, and the
+//              queue keeps its slot order, which is what keeps the slot-indexed path state coalesced (modes 0 and 2 only)
+hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, int mode, bool compact);
 hipError_t launch_reduce_streams(hipStream_t s, const float4 *acc, float4 *tiles, uint32_t slots_per_stream, uint32_t streams);
 hipError_t launch_assemble(hipStream_t s, const float4 *gathered, uint32_t nranks, uint32_t slots_per_rank,
                            uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, float inv_spp,

@@ -311,6 +311,31 @@ def test_shard_groups_on_separate_streams(P, pto, monkeypatch):
     assert all(f[0] == frames[0][0] and np.array_equal(f[1], frames[0][1]) for f in frames)
 
 
+@pytest.mark.parametrize("flags", [0, 4])  # one-ray-per-lane and lane-packing extend kernels both have to skip the holes
+def test_queue_compaction_policy_is_invisible(P, pto, monkeypatch, flags):
+    """PTRT_COMPACT: queues carried over in place with holes (0 = never re-packed), re-packed every iteration (2), or
+    re-packed when alive/length < 0.9 — scheduling only: frame and ray count stay the oracle's. The streams end at
+    different iterations (spp 7 over 4 streams, Russian roulette), so the in-place runs do see holes."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 4, 200, 150)
+    p = P.make_params(200, 150, spp=7, max_depth=12, streams=4, flags=flags)
+    frames = []
+    for thr in ("0", "2", "0.9", "0.5"):
+        monkeypatch.setenv("PTRT_COMPACT", thr)
+        r = P.Renderer(P.Window(200, 150)); r.Init()
+        try:
+            r.SetScene(sd, 0); r.Params = p
+            st = r.Render(0.0)
+            frames.append((st.rays, r.ReadFramebuffer(), st.reserved[1], st.iterations))
+            if thr == "0":
+                info = r.BvhInfo()
+                ref, ost = pto.render(pto.Scene(sd, (info.width,) + r.BvhRead()), p)
+                assert ost.rays == st.rays and np.array_equal(frames[-1][1], ref)
+        finally:
+            r.Dispose()
+    assert all(f[0] == frames[0][0] and np.array_equal(f[1], frames[0][1]) for f in frames)
+    assert frames[0][2] == 0 and frames[1][2] == frames[1][3] and 0 < frames[2][2] < frames[2][3]
+
+
 def test_image_output(P, pto, renderer, tmp_path):
     """PPM carries the reference's R8G8B8A8Unorm quantisation (Renderer.cs:124), PFM the linear floats."""
     renderer.Params = P.make_params(97, 41, mode=P.native.PT_REFERENCE_SPHERE)
