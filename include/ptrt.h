@@ -60,8 +60,10 @@ enum {
     PT_FLAG_EXTEND_SIMPLE = 8u,   /* force the one-ray-per-lane extend kernel. Neither flag: probed per scene (pt_stats.reserved[0]) */
     PT_FLAG_BUCKET_SPECULAR = 32u, /* shade metal / dielectric hits from per-kind bucket queues (wave-uniform BSDF code) instead of
                                      in queue order. Slower on MI355X: re-queued slots scramble the queue order and state access
-                                     loses its coalescing; kept for comparison */
-    PT_FLAG_ACCUMULATE = 16u      /* progressive rendering: keep the sums of the previous call(s) (same size/rank/streams/seed,
+                                     loses its coalescing; kept for comparison (implies PT_FLAG_SPLIT_KERNELS) */
+    PT_FLAG_SPLIT_KERNELS = 64u,  /* run extend and shade as two kernels per iteration (hit records through HBM) instead of shading
+                                     inside the extend kernel; same frame, lets PT_FLAG_PROFILE_KERNELS time the two separately */
+    PT_FLAG_ACCUMULATE = 16u     /* progressive rendering: keep the sums of the previous call(s) (same size/rank/streams/seed,
                                      sample_offset = samples so far) and show the mean over all samples — the converging analogue
                                      of the reference's render-every-frame loop (App.cs:39-42) */
 };

@@ -428,6 +428,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     // rays per wavefront of the lane-packing kernel: 256 once several sample streams keep the queues long, else 128 (measured)
     const uint32_t packed_chunk = chunk_env >= 64u ? chunk_env : ((p->streams >= 4u) ? 256u : 128u);
     const bool bucket_specular = (p->flags & PT_FLAG_BUCKET_SPECULAR) != 0;
+    const bool split_kernels = bucket_specular || (p->flags & PT_FLAG_SPLIT_KERNELS) != 0;
     const uint32_t forced_choice =(p->flags & PT_FLAG_EXTEND_PACKED) ? 2u : (p->flags & PT_FLAG_EXTEND_SIMPLE) ? 1u : 0u;
 
     if (p->mode == PT_REFERENCE_SPHERE) {
@@ -537,7 +538,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             Loop &L = loops[g];
             if (L.done) continue;
             if (L.iters >= max_iters) return fail(c, PT_ERR_INTERNAL, "wavefront loop did not drain after %u iterations", L.iters);
-            const uint32_t parity = L.iters & 1u;
+            const uint32_t it = L.iters;
             PathState pg = ps;
             pg.shard_base = L.base; pg.shard_count = per_group;
             hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -548,22 +549,25 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             }
             const bool probing = g == 0u && ext_choice == 0u && (L.iters == 2u || L.iters == 3u);
             const bool use_packed = ext_choice == 2u || (probing && L.iters == 3u);
-            if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
-            HIP_TRY(c, launch_extend(L.stream, sc, pg, parity, L.bound, count, use_packed ? packed_chunk : 0u));
-            if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u + 1u], L.stream));
-            if (profile) HIP_TRY(c, hipEventRecord(e1, L.stream));
-            const bool compact = L.compact_next || c->compact_below > 1.0 || (bucket_specular && s->has_specular); // buckets re-append: no fixed positions
+            const bool compact = L.compact_next || c->compact_below > 1.0 || bucket_specular; // buckets re-append: no fixed positions
             if (compact) { L.compact_next = false; L.last_compact = (int64_t)L.iters; ++n_compactions; }
-            if (!s->has_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 0, compact));      // Lambert only: lean kernel
-            else if (!bucket_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 2, compact)); // all kinds in queue order
-            else {
-                HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 0, true));
-                HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, parity, L.bound, 1, true)); // metal + dielectric buckets
+            // One kernel per iteration by default: the one-ray-per-lane k_extend shades its own hits (mode 0: Lambert-only
+            // scene, lean code; 2: all kinds). The lane-packing kernel and the bucketed pipeline keep k_shade as a second kernel.
+            const int shade_mode = s->has_specular ? 2 : 0;
+            const bool fused = !split_kernels && !use_packed;
+            if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
+            HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, use_packed ? packed_chunk : 0u, fused ? shade_mode : -1, compact));
+            if (profile) HIP_TRY(c, hipEventRecord(e1, L.stream));
+            if (!fused && !bucket_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, it, L.bound, shade_mode, compact));
+            else if (!fused) {
+                HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, it, L.bound, 0, true));
+                HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, it, L.bound, 1, true)); // metal + dielectric buckets
             }
+            if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u + 1u], L.stream)); // the whole iteration, either way
             if (profile) HIP_TRY(c, hipEventRecord(e2, L.stream));
             const uint32_t ring = L.iters % kLag;
             uint32_t *h_ring = c->h_counts + ((size_t)g * kLag + ring) * kRingWords;
-            HIP_TRY(c, hipMemcpyAsync(h_ring, c->counters.p + cnt_ext_index(parity ^ 1u, L.base), sizeof(uint32_t) * per_group * kCounterStride,
+            HIP_TRY(c, hipMemcpyAsync(h_ring, c->counters.p + cnt_ext_index((it + 1u) % 3u, L.base), sizeof(uint32_t) * per_group * kCounterStride,
                                       hipMemcpyDeviceToHost, L.stream));
             HIP_TRY(c, hipEventRecord(c->ev_lag[g][ring], L.stream));
             ++L.iters;
@@ -613,7 +617,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     if (hc[kCntError]) return fail(c, PT_ERR_INTERNAL, "device error flag 0x%x (1 = traversal stack overflow, 2 = step limit)", hc[kCntError]);
     auto u64_at = [&](uint32_t w) { return (uint64_t)hc[w] | ((uint64_t)hc[w + 1] << 32); };
     for (uint32_t sh = 0; sh < kShards; ++sh) {
-        if (hc[cnt_alive_index(0, sh)] || hc[cnt_alive_index(1, sh)]) return fail(c, PT_ERR_INTERNAL, "extend queue of shard %u not empty at frame end", sh);
+        if (hc[cnt_alive_index(0, sh)] || hc[cnt_alive_index(1, sh)] || hc[cnt_alive_index(2, sh)]) return fail(c, PT_ERR_INTERNAL, "extend queue of shard %u not empty at frame end", sh);
         out.rays += u64_at(cnt_rays_index(sh));
     }
     float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));

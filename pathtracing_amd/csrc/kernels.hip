@@ -166,20 +166,142 @@ PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, floa
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int L, bool COUNT>
-__global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState ps, uint32_t parity)
+// One path vertex (docs/SPEC.md §5): emission / sky, BSDF sample, throughput, Russian roulette, and in-place
+// regeneration of the stream's next camera sample when the path ends. (o, d, t, ref) = the ray and its closest hit.
+// Returns true when the slot holds a ray for the next iteration (its state has been written back).
+//   SHADE_QUEUE   : Lambert and misses; a specular hit sets `defer` to its bucket and leaves the state untouched
+//   SHADE_BUCKETS : the hit's kind is `b` (wave-uniform)
+//   SHADE_INLINE  : every kind, by a divergent branch
+enum ShadeMode { SHADE_NONE = -1, SHADE_QUEUE = 0, SHADE_BUCKETS = 1, SHADE_INLINE = 2 };
+template <int MODE>
+PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t slot, V3 o, V3 d, float t, uint32_t ref,
+                      uint32_t b, uint32_t &defer)
 {
+    const float4 TK = ps.thr[slot];
+    const uint32_t sdv = ps.sd[slot];
+    V3 T = xyz(TK);
+    uint32_t key = __float_as_uint(TK.w), sample = sdv >> 8, depth = (sdv & 255u) + 1u;
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool touched = false, term = false, alive = false;
+    auto add = [&](V3 L) {
+        if (!touched) { A = ps.acc[slot]; touched = true; }
+        A.x = fma_(T.x, L.x, A.x); A.y = fma_(T.y, L.y, A.y); A.z = fma_(T.z, L.z, A.z);
+    };
+
+    if (ref == PT_MISS) {
+        add(v3(sc.sky[0], sc.sky[1], sc.sky[2]));
+        term = true;
+    } else {
+        const V3 P = madd(t, d, o);
+        V3 ng;
+        uint32_t mat;
+        if (ref < sc.n_tris) {
+            const float4 ts = sc.tri_shade[ref]; // normalize(cross(e1,e2)) precomputed at commit, bit-identical
+            ng = xyz(ts);
+            mat = __float_as_uint(ts.w);
+        } else {
+            const uint32_t j = ref - sc.n_tris;
+            const float4 s = sc.spheres[j];
+            const float ir = 1.0f / s.w;
+            ng = v3((P.x - s.x) * ir, (P.y - s.y) * ir, (P.z - s.z) * ir);
+            mat = sc.sph_mat[j];
+        }
+        const bool front = dot(ng, d) < 0.0f;
+        const V3 n = front ? ng : neg(ng);
+        const float4 m0 = sc.mats[(size_t)mat * 3], m1 = sc.mats[(size_t)mat * 3 + 1], m2 = sc.mats[(size_t)mat * 3 + 2];
+        const V3 alb = v3(m0.y, m0.z, m0.w), emi = xyz(m1);
+        const uint32_t kind = __float_as_uint(m0.x);
+        if (MODE == SHADE_QUEUE && kind != (uint32_t)PT_LAMBERT) { defer = 1u + kind; return false; } // shaded by k_shade<SHADE_BUCKETS>
+        if (emi.x != 0.0f || emi.y != 0.0f || emi.z != 0.0f) add(emi);
+        if (depth >= fp.max_depth) term = true;
+        else {
+            const uint32_t bb = depth - 1u;
+            V3 wi = d, W = v3(1.f, 1.f, 1.f);
+            float side = 1.0f;
+            bool ok = true;
+            const uint32_t bk = MODE == SHADE_QUEUE ? (uint32_t)B_LAMBERT : MODE == SHADE_BUCKETS ? b : 1u + kind;
+            if (bk == B_LAMBERT) sample_lambert(alb, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
+            else if (bk == B_METAL) ok = sample_metal(alb, m1.w, d, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
+            else sample_dielectric(alb, m2.x, d, n, front, u01(key, 6u + 4u * bb), wi, W, side);
+            if (!ok) term = true;
+            else {
+                T = v3(T.x * W.x, T.y * W.y, T.z * W.z);
+                if (!(fmax_(T.x, fmax_(T.y, T.z)) > 0.0f)) term = true;
+                else if (depth >= fp.rr_start) {
+                    const float qrr = fmin_(fmax_(T.x, fmax_(T.y, T.z)), 0.95f);
+                    if (!(u01(key, 7u + 4u * bb) < qrr)) term = true;
+                    else { const float iq = 1.0f / qrr; T = v3(T.x * iq, T.y * iq, T.z * iq); }
+                }
+                if (!term) { o = madd(side * fp.ray_eps, n, P); d = wi; }
+            }
+        }
+    }
+
+    if (term) {
+        if (!touched) { A = ps.acc[slot]; touched = true; }
+        A.w += 1.0f;
+        sample += fp.streams;
+        if (sample < fp.spp) { // regenerate this stream's next sample of the pixel in place
+            uint32_t x = 0, y = 0;
+            slot_pixel(slot, fp, x, y);
+            key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset + sample);
+            camera_ray_of(sc.cam, x, y, key, o, d);
+            T = v3(1.f, 1.f, 1.f);
+            depth = 0;
+            alive = true;
+        }
+    } else alive = true;
+
+    if (touched) ps.acc[slot] = A;
+    if (alive) {
+        ps.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
+        ps.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
+        ps.thr[slot] = make_float4(T.x, T.y, T.z, __uint_as_float(key));
+        ps.sd[slot] = (sample << 8) | depth;
+    }
+    return alive;
+}
+
+// Hand a lane's surviving slot to the next iteration's extend queue (reached by all lanes of the workgroup).
+//   compact : append (ballot + one returning atomic per wavefront) -> dense queue, order scrambled by wavefront
+//   else    : write position `gid` of the next queue (slot or hole); the shard's length carries over
+PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint32_t *q_next, uint32_t gid, uint32_t total, bool alive,
+                       uint32_t slot, bool compact)
+{
+    if (compact) wave_push(&ps.counters[cnt_ext_index(cnext, shard)], q_next, alive, slot);
+    else {
+        if (gid < total) q_next[gid] = alive ? slot : kInvalidSlot;
+        if (gid == 0) ps.counters[cnt_ext_index(cnext, shard)] = total;
+    }
+    const uint64_t m = __ballot(alive);
+    if (m && lane_id() == 0u) atomicAdd(&ps.counters[cnt_alive_index(cnext, shard)], (uint32_t)__popcll(m));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_extend<L, COUNT, FUSE>: closest hit of every ray of the iteration's extend queue (one ray per lane, LDS traversal stack).
+//   FUSE == SHADE_NONE : writes the hit record; k_shade walks the same queue afterwards
+//   FUSE == SHADE_QUEUE (Lambert-only scenes) / SHADE_INLINE : the lane shades its own hit straight from registers and
+//       queues its slot for the next iteration. With queues carried in place this needs nothing from any other lane, and
+//       it takes the hit record (8 B written + read), the second read of the ray (32 B), one queue pass and one launch per
+//       iteration out of the frame; waves that finish traversal early stream their shading traffic to HBM while the
+//       others are still gathering nodes.
+// Counters are triple-buffered by iteration (cur = it % 3 is read, next is filled, the third is zeroed for the
+// iteration after), because a fused kernel fills `next` while other workgroups of the same launch are still starting.
+template <int L, bool COUNT, int FUSE>
+__global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint32_t compact)
+{
+    const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u, czero = (it + 2u) % 3u;
     constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
     __shared__ int32_t s_stack[kStackLds * kExtBlock];
     const uint32_t shard = blockIdx.y + ps.shard_base;
-    const uint32_t n = ps.counters[cnt_ext_index(parity, shard)];
+    const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)];
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * kExtBlock + tid;          // index inside the shard's queue
     if (gid == 0) {
-        ps.counters[cnt_ext_index(parity ^ 1u, shard)] = 0u;   // next iteration's queue: filled by k_shade after us
-        ps.counters[cnt_alive_index(parity ^ 1u, shard)] = 0u;
+        ps.counters[cnt_ext_index(czero, shard)] = 0u;         // the queue after next
+        ps.counters[cnt_alive_index(czero, shard)] = 0u;
         unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
-        *rays += ps.counters[cnt_alive_index(parity, shard)];  // only this thread ever touches rays[shard]
+        *rays += ps.counters[cnt_alive_index(ccur, shard)];    // only this thread ever touches rays[shard]
     }
     if (blockIdx.x * kExtBlock >= n) return;
     const size_t qbase = (size_t)shard * ps.shard_cap;
@@ -189,10 +311,11 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
 
     Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
     unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0;
+    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
 
     if (active) {
         const float4 O = ps.ray_o[slot], D = ps.ray_d[slot];
-        const V3 o = xyz(O), d = xyz(D);
+        o = xyz(O); d = xyz(D);
 
         for (uint32_t j = 0; j < sc.n_spheres; ++j) { // uniform index => scalar loads
             sphere_test(sc.spheres[j], sc.n_tris + j, o, d, h);
@@ -242,12 +365,18 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
             }
         }
 
-        ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref)); // k_shade<false> walks the same queue in the same order
+        if (FUSE == SHADE_NONE) ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref)); // k_shade walks the same queue in the same order
         if (COUNT) {
             atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
             atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
             atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);
         }
+    }
+    if (FUSE != SHADE_NONE) {
+        bool alive = false;
+        uint32_t defer = 0u;
+        if (active) alive = shade_one<FUSE>(sc, ps, fp, slot, o, d, h.t, h.ref, B_LAMBERT, defer);
+        queue_next(ps, shard, cnext, ps.q_ext[parity ^ 1u] + qbase, gid, n, alive, slot, compact != 0u);
     }
 }
 
@@ -264,18 +393,19 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
 constexpr uint32_t kRefillIdle = PT_REFILL_IDLE;
 
 template <int L, bool COUNT>
-__global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState ps, uint32_t parity, uint32_t chunk)
+__global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState ps, uint32_t it, uint32_t chunk)
 {
     constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
     __shared__ int32_t s_stack[kStackLds * 64];
+    const uint32_t parity = it & 1u, ccur = it % 3u, czero = (it + 2u) % 3u;
     const uint32_t shard = blockIdx.y + ps.shard_base;
-    const uint32_t n = ps.counters[cnt_ext_index(parity, shard)];
+    const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)];
     const uint32_t lane = threadIdx.x;
     if (blockIdx.x == 0 && lane == 0) {
-        ps.counters[cnt_ext_index(parity ^ 1u, shard)] = 0u;
-        ps.counters[cnt_alive_index(parity ^ 1u, shard)] = 0u;
+        ps.counters[cnt_ext_index(czero, shard)] = 0u;
+        ps.counters[cnt_alive_index(czero, shard)] = 0u;
         unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
-        *rays += ps.counters[cnt_alive_index(parity, shard)];
+        *rays += ps.counters[cnt_alive_index(ccur, shard)];
     }
     uint32_t next = blockIdx.x * chunk;                       // wave-uniform cursor into the shard's queue
     if (next >= n) return;
@@ -385,11 +515,12 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
 //                          scrambles the queue's slot order a little more every iteration; measured on Cornell + glass + metal,
 //                          the same 16.6 M-ray launch went from 0.78 ms to 2.15 ms (shade) and 0.32 to 0.74 ms (extend) within
 //                          30 iterations as slot-indexed state lost its coalescing. Order beats divergence here.
-enum ShadeMode { SHADE_QUEUE = 0, SHADE_BUCKETS = 1, SHADE_INLINE = 2 };
+// These run after k_extend<.., SHADE_NONE> or k_extend_packed; the default pipeline shades inside k_extend (FUSE).
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, FrameParams fp, uint32_t parity, uint32_t compact)
+__global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint32_t compact)
 {
     constexpr bool SPEC = MODE == SHADE_BUCKETS;
+    const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u;
     const uint32_t shard = blockIdx.y + ps.shard_base;
     const size_t qbase = (size_t)shard * ps.shard_cap;
     uint32_t total, c0 = 0u;
@@ -398,7 +529,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
         total = c0 + ps.counters[cnt_bucket_index(parity, B_DIELECTRIC, shard)];
         if (blockIdx.x == 0 && threadIdx.x < 2u) // the other parity's buckets were consumed by the previous k_shade<true>
             ps.counters[cnt_bucket_index(parity ^ 1u, B_METAL + threadIdx.x, shard)] = 0u;
-    } else total = ps.counters[cnt_ext_index(parity, shard)];
+    } else total = ps.counters[cnt_ext_index(ccur, shard)];
     // SPEC: a small fixed grid strides over the (usually short, unknown-length) specular buckets, so an empty bucket
     // costs a few hundred trivial blocks instead of one per 256 queue slots. !SPEC: exactly one pass, grid sized by the host.
     for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
@@ -414,109 +545,10 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
 
     if (active) {
         const float2 hr = ps.hit[slot];
-        const float4 O = ps.ray_o[slot], D = ps.ray_d[slot], TK = ps.thr[slot];
-        const uint32_t sdv = ps.sd[slot];
-        V3 o = xyz(O), d = xyz(D), T = xyz(TK);
-        uint32_t key = __float_as_uint(TK.w), sample = sdv >> 8, depth = (sdv & 255u) + 1u;
-        const float t = hr.x;
-        const uint32_t ref = __float_as_uint(hr.y);
-        float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool touched = false, term = false;
-        auto add = [&](V3 L) {
-            if (!touched) { A = ps.acc[slot]; touched = true; }
-            A.x = fma_(T.x, L.x, A.x); A.y = fma_(T.y, L.y, A.y); A.z = fma_(T.z, L.z, A.z);
-        };
-
-        if (ref == PT_MISS) {
-            add(v3(sc.sky[0], sc.sky[1], sc.sky[2]));
-            term = true;
-        } else {
-            const V3 P = madd(t, d, o);
-            V3 ng;
-            uint32_t mat;
-            if (ref < sc.n_tris) {
-                const float4 ts = sc.tri_shade[ref]; // normalize(cross(e1,e2)) precomputed at commit, bit-identical
-                ng = xyz(ts);
-                mat = __float_as_uint(ts.w);
-            } else {
-                const uint32_t j = ref - sc.n_tris;
-                const float4 s = sc.spheres[j];
-                const float ir = 1.0f / s.w;
-                ng = v3((P.x - s.x) * ir, (P.y - s.y) * ir, (P.z - s.z) * ir);
-                mat = sc.sph_mat[j];
-            }
-            const bool front = dot(ng, d) < 0.0f;
-            const V3 n = front ? ng : neg(ng);
-            const float4 m0 = sc.mats[(size_t)mat * 3], m1 = sc.mats[(size_t)mat * 3 + 1], m2 = sc.mats[(size_t)mat * 3 + 2];
-            const V3 alb = v3(m0.y, m0.z, m0.w), emi = xyz(m1);
-            const uint32_t kind = __float_as_uint(m0.x);
-            if (MODE == SHADE_QUEUE && kind != (uint32_t)PT_LAMBERT) defer = 1u + kind; // shaded by k_shade<SHADE_BUCKETS>; this lane leaves everything untouched
-            else {
-            if (emi.x != 0.0f || emi.y != 0.0f || emi.z != 0.0f) add(emi);
-            if (depth >= fp.max_depth) term = true;
-            else {
-                const uint32_t bb = depth - 1u;
-                V3 wi = d, W = v3(1.f, 1.f, 1.f);
-                float side = 1.0f;
-                bool ok = true;
-                const uint32_t bk = MODE == SHADE_QUEUE ? (uint32_t)B_LAMBERT : MODE == SHADE_BUCKETS ? b : 1u + kind;
-                if (bk == B_LAMBERT) sample_lambert(alb, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
-                else if (bk == B_METAL) ok = sample_metal(alb, m1.w, d, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
-                else sample_dielectric(alb, m2.x, d, n, front, u01(key, 6u + 4u * bb), wi, W, side);
-                if (!ok) term = true;
-                else {
-                    T = v3(T.x * W.x, T.y * W.y, T.z * W.z);
-                    if (!(fmax_(T.x, fmax_(T.y, T.z)) > 0.0f)) term = true;
-                    else if (depth >= fp.rr_start) {
-                        const float qrr = fmin_(fmax_(T.x, fmax_(T.y, T.z)), 0.95f);
-                        if (!(u01(key, 7u + 4u * bb) < qrr)) term = true;
-                        else { const float iq = 1.0f / qrr; T = v3(T.x * iq, T.y * iq, T.z * iq); }
-                    }
-                    if (!term) { o = madd(side * fp.ray_eps, n, P); d = wi; }
-                }
-            }
-            }
-        }
-
-        if (defer) {
-            // nothing: the path state stays as k_extend left it
-        } else if (term) {
-            if (!touched) { A = ps.acc[slot]; touched = true; }
-            A.w += 1.0f;
-            sample += fp.streams;
-            if (sample < fp.spp) { // regenerate this stream's next sample of the pixel in place
-                uint32_t x = 0, y = 0;
-                slot_pixel(slot, fp, x, y);
-                key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset + sample);
-                camera_ray_of(sc.cam, x, y, key, o, d);
-                T = v3(1.f, 1.f, 1.f);
-                depth = 0;
-                alive = true;
-            }
-        } else alive = true;
-
-        if (touched) ps.acc[slot] = A;
-        if (alive) {
-            ps.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
-            ps.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
-            ps.thr[slot] = make_float4(T.x, T.y, T.z, __uint_as_float(key));
-            ps.sd[slot] = (sample << 8) | depth;
-        }
+        const float4 O = ps.ray_o[slot], D = ps.ray_d[slot];
+        alive = shade_one<MODE>(sc, ps, fp, slot, xyz(O), xyz(D), hr.x, __float_as_uint(hr.y), b, defer);
     }
-    if (SPEC || compact) {
-        wave_push(&ps.counters[cnt_ext_index(parity ^ 1u, shard)], ps.q_ext[parity ^ 1u] + qbase, alive, slot);
-        const uint64_t m = __ballot(alive);
-        if (m && (lane_id() == 0u)) atomicAdd(&ps.counters[cnt_alive_index(parity ^ 1u, shard)], (uint32_t)__popcll(m));
-    } else {
-        // carry the queue over in place: position gid keeps its slot for as long as the path lives. No returning atomic,
-        // and lane <-> slot stays the generation order (8x8 pixel blocks of one stream per wavefront) for the whole frame.
-        if (gid < total) ps.q_ext[parity ^ 1u][qbase + gid] = alive ? slot : kInvalidSlot;
-        const uint32_t n_alive = (uint32_t)__syncthreads_count(alive);
-        if (threadIdx.x == 0) {
-            if (n_alive) atomicAdd(&ps.counters[cnt_alive_index(parity ^ 1u, shard)], n_alive);
-            if (blockIdx.x == 0) ps.counters[cnt_ext_index(parity ^ 1u, shard)] = total;
-        }
-    }
+    queue_next(ps, shard, cnext, ps.q_ext[parity ^ 1u] + qbase, gid, total, alive, slot, SPEC || compact);
     if (MODE == SHADE_QUEUE) {
         wave_push(&ps.counters[cnt_bucket_index(parity, B_METAL, shard)], ps.q_bucket[B_METAL] + qbase, defer == B_METAL, slot);
         wave_push(&ps.counters[cnt_bucket_index(parity, B_DIELECTRIC, shard)], ps.q_bucket[B_DIELECTRIC] + qbase, defer == B_DIELECTRIC, slot);
@@ -578,36 +610,37 @@ hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState
     return hipGetLastError();
 }
 
-hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count,
-                         uint32_t packed_chunk)
+template <int L, bool C>
+static void extend_lc(hipStream_t s, dim3 grid, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t chunk, int fuse,
+                      uint32_t cm)
+{
+    if (chunk) hipLaunchKernelGGL((k_extend_packed<L, C>), grid, dim3(64), 0, s, sc, ps, it, chunk);
+    else if (fuse == SHADE_QUEUE) hipLaunchKernelGGL((k_extend<L, C, SHADE_QUEUE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm);
+    else if (fuse == SHADE_INLINE) hipLaunchKernelGGL((k_extend<L, C, SHADE_INLINE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm);
+    else hipLaunchKernelGGL((k_extend<L, C, SHADE_NONE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm);
+}
+
+hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t shard_bound, bool count,
+                         uint32_t packed_chunk, int fuse, bool compact)
 {
     // packed_chunk >= 64: rays per wavefront of the lane-packing kernel (PT_FLAG_EXTEND_PACKED); 0: one ray per lane.
     // Measured on MI355X: packing raises lane utilisation but is slower at every chunk size, because the
     // kernel is bound by outstanding divergent node fetches and fewer waves means fewer of them; it stays selectable.
-#define PT_LAUNCH_BY_LAYOUT(KERNEL, GRID, BLOCK, ...)                                                                    \
-    switch (sc.bvh_width) {                                                                                              \
-    case PT_BVH_WIDTH_2:  if (count) hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_2, true>), GRID, BLOCK, 0, s, __VA_ARGS__);  \
-                          else hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_2, false>), GRID, BLOCK, 0, s, __VA_ARGS__); break; \
-    case PT_BVH_WIDTH_4:  if (count) hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_4, true>), GRID, BLOCK, 0, s, __VA_ARGS__);  \
-                          else hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_4, false>), GRID, BLOCK, 0, s, __VA_ARGS__); break; \
-    case PT_BVH_WIDTH_4Q: if (count) hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_4Q, true>), GRID, BLOCK, 0, s, __VA_ARGS__); \
-                          else hipLaunchKernelGGL((KERNEL<PT_BVH_WIDTH_4Q, false>), GRID, BLOCK, 0, s, __VA_ARGS__); break; \
-    default: return hipErrorInvalidValue;                                                                                \
+    const uint32_t chunk = packed_chunk >= 64u ? packed_chunk : 0u, per_block = chunk ? chunk : kExtBlock;
+    const dim3 grid(shard_bound ? (shard_bound + per_block - 1) / per_block : 1u, ps.shard_count);
+    const uint32_t cm = compact ? 1u : 0u;
+    switch (sc.bvh_width) {
+    case PT_BVH_WIDTH_2:  count ? extend_lc<PT_BVH_WIDTH_2, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm) : extend_lc<PT_BVH_WIDTH_2, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm); break;
+    case PT_BVH_WIDTH_4:  count ? extend_lc<PT_BVH_WIDTH_4, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm) : extend_lc<PT_BVH_WIDTH_4, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm); break;
+    case PT_BVH_WIDTH_4Q: count ? extend_lc<PT_BVH_WIDTH_4Q, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm) : extend_lc<PT_BVH_WIDTH_4Q, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm); break;
+    default: return hipErrorInvalidValue;
     }
-    if (packed_chunk >= 64u) {
-        const uint32_t chunk = packed_chunk;
-        const dim3 pgrid(shard_bound ? (shard_bound + chunk - 1) / chunk : 1u, ps.shard_count), pblock(64);
-        PT_LAUNCH_BY_LAYOUT(k_extend_packed, pgrid, pblock, sc, ps, parity, chunk)
-        return hipGetLastError();
-    }
-    const dim3 grid(shard_bound ? (shard_bound + kExtBlock - 1) / kExtBlock : 1u, ps.shard_count), block(kExtBlock);
-    PT_LAUNCH_BY_LAYOUT(k_extend, grid, block, sc, ps, parity)
-#undef PT_LAUNCH_BY_LAYOUT
     return hipGetLastError();
 }
 
-hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, int mode, bool compact)
+hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t shard_bound, int mode, bool compact)
 {
+    const uint32_t parity = it; // k_shade derives queue parity and counter rotation from the iteration index
     const dim3 grid(blocks_for(shard_bound), ps.shard_count), block(kBlock);
     const dim3 sgrid(std::min(blocks_for(shard_bound), 16u), ps.shard_count); // grid-stride over the specular buckets
     const uint32_t cm = compact ? 1u : 0u;

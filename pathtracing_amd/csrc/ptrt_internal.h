@@ -30,9 +30,9 @@ constexpr uint32_t kCounterStride = 16;            // u32 words between counters
 
 enum Bucket : uint32_t { B_MISS = 0, B_LAMBERT = 1, B_METAL = 2, B_DIELECTRIC = 3, B_COUNT = 4 };
 
-// counters block (u32 words). ext[parity][shard], bucket[parity][bucket][shard], rays[shard] (u64), then globals.
+// counters block (u32 words). ext[iteration % 3][shard], bucket[parity][bucket][shard], rays[shard] (u64), then globals.
 constexpr uint32_t kCntExt = 0;
-constexpr uint32_t kCntBucket = kCntExt + 2 * kShards * kCounterStride;
+constexpr uint32_t kCntBucket = kCntExt + 3 * kShards * kCounterStride;
 constexpr uint32_t kCntRays = kCntBucket + 2 * B_COUNT * kShards * kCounterStride;
 constexpr uint32_t kCntGlobals = kCntRays + kShards * kCounterStride;
 constexpr uint32_t kCntError = kCntGlobals + 0;
@@ -94,12 +94,16 @@ struct FrameParams {
 // `shard_bound` = upper bound of any shard's queue length for this launch.
 hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4 *out_f, uint32_t *out_rgba8);
 hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp);
-hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, uint32_t parity, uint32_t shard_bound, bool count, uint32_t packed_chunk);
+// `it` = iteration index of the wavefront loop: queues alternate by it & 1, queue counters rotate by it % 3.
+// fuse: -1 = extend only (k_shade follows); 0 / 2 = k_extend also shades (Lambert-only / all kinds) and queues the next
+// iteration, honouring `compact` like launch_shade. Ignored (treated as -1) by the lane-packing kernel.
+hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t shard_bound, bool count,
+                         uint32_t packed_chunk, int fuse, bool compact);
 // mode: 0 = queue order, specular kinds deferred to buckets; 1 = the specular buckets; 2 = queue order, everything shaded in place
 // compact: 1 = survivors are appended densely to the next queue (ballot + one returning atomic per wavefront);
 //          0 = every lane writes its own position of the next queue (slot or kInvalidSlot): no returning atomics, and the
 //              queue keeps its slot order, which is what keeps the slot-indexed path state coalesced (modes 0 and 2 only)
-hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t parity, uint32_t shard_bound, int mode, bool compact);
+hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t shard_bound, int mode, bool compact);
 hipError_t launch_reduce_streams(hipStream_t s, const float4 *acc, float4 *tiles, uint32_t slots_per_stream, uint32_t streams);
 hipError_t launch_assemble(hipStream_t s, const float4 *gathered, uint32_t nranks, uint32_t slots_per_rank,
                            uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, float inv_spp,
