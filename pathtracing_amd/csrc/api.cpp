@@ -68,7 +68,8 @@ struct pt_context {
     uint32_t groups = 1;                        // PTRT_GROUPS (1, 2, 4) overrides. 2 measured +2.5 % (Cornell 1M) ... +14 % (soup);
                                                 // the default stays 1 so that a launch timed by HIP events, by rocprofv3 and
                                                 // in the benchmark frame is one and the same thing (kernels alone on the GPU)
-    double compact_below = 0.75;                // PTRT_COMPACT overrides: k_shade re-packs a loop's queues once alive/length drops
+    uint32_t bounces = 4;                       // PTRT_BOUNCES (1..64): path vertices per launch of the fused kernel (state in registers)
+    double compact_below = 0.75;               // PTRT_COMPACT overrides: k_shade re-packs a loop's queues once alive/length drops
                                                 // below this (>1 = every iteration, 0 = never); otherwise queues are carried in place
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_probe[4] = {}; // brackets of the two probe iterations that pick the extend kernel
@@ -91,7 +92,7 @@ struct pt_scene {
     std::vector<uint8_t> packed_nodes;   // layout PT_BVH_WIDTH_4Q: the 64-byte nodes that are uploaded / read back
     const void *node_data() const { return layout == PT_BVH_WIDTH_4Q ? (const void *)packed_nodes.data() : (const void *)bvh.slots.data(); }
     uint64_t node_bytes() const { return layout == PT_BVH_WIDTH_4Q ? packed_nodes.size() : bvh.slots.size() * sizeof(BvhSlot); }
-    DevBuf<float4> d_nodes, d_tris, d_tri_shade, d_spheres, d_mats;
+    DevBuf<float4> d_nodes, d_tris, d_spheres, d_mats;
     bool has_specular = false;
     uint32_t ext_choice = 0;             // extend kernel picked by the probe of an earlier frame (0 = none yet, 1 = simple, 2 = packed)
     DevBuf<uint32_t> d_sph_mat;
@@ -179,6 +180,7 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
     }
     bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * (kFinalOffset + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
     if (const char *e = getenv("PTRT_GROUPS")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4) c->groups = (uint32_t)g; }
+    if (const char *e = getenv("PTRT_BOUNCES")) { const int b = atoi(e); if (b >= 1 && b <= 64) c->bounces = (uint32_t)b; }
     if (const char *e = getenv("PTRT_COMPACT")) { const double v = atof(e); if (v >= 0.0 && v <= 2.0) c->compact_below = v; }
     for (uint32_t g = 0; ok && g < kMaxGroups; ++g) {
         ok = hipStreamCreateWithFlags(&c->group_stream[g], hipStreamNonBlocking) == hipSuccess &&
@@ -234,7 +236,7 @@ void pt_scene_destroy(pt_scene *s)
 {
     if (!s) return;
     if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
-    s->d_nodes.release(); s->d_tris.release(); s->d_tri_shade.release(); s->d_spheres.release(); s->d_mats.release(); s->d_sph_mat.release();
+    s->d_nodes.release(); s->d_tris.release();s->d_spheres.release(); s->d_mats.release(); s->d_sph_mat.release();
     delete s;
 }
 
@@ -332,26 +334,27 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     HIP_TRY(c, hipSetDevice(c->device));
     static_assert(sizeof(BvhSlot) == 32 && sizeof(BvhTri) == 48 && sizeof(pt_material) == 48, "blob layout");
     HIP_TRY(c, s->d_nodes.ensure((size_t)(s->node_bytes() / 16)));
-    HIP_TRY(c, s->d_tris.ensure(s->bvh.tris.size() * 3 + 1)); // +1 row: k_extend always fetches 4 rows, a triangle has 3
-    HIP_TRY(c, s->d_tri_shade.ensure(s->bvh.tris.size()));
-    {   // per-triangle shading record: ng = normalize(cross(e1,e2)) in exactly the op order of docs/SPEC.md §0 (fma, IEEE
-        // sqrt and divide), so the bits equal what the kernel would compute from e1,e2; 16 B instead of two 16-B rows.
-        std::vector<float> ts(s->bvh.tris.size() * 4);
+    HIP_TRY(c, s->d_tris.ensure(s->bvh.tris.size() * 4));
+    {   // Device triangle record = one 64-byte line: the blob's three rows (docs/SPEC.md §4.1) + a shading row. A 48-byte
+        // record straddles two cache lines 3 times out of 4 when k_extend fetches it; a padded one never does, and the
+        // row that pads it is the one k_shade wants next. Shading row: ng = normalize(cross(e1,e2)) in exactly the op order
+        // of docs/SPEC.md §0 (fma, IEEE sqrt and divide), so the bits equal what the kernel would compute from e1,e2.
+        std::vector<float> rec(s->bvh.tris.size() * 16);
         for (size_t i = 0; i < s->bvh.tris.size(); ++i) {
             const BvhTri &t = s->bvh.tris[i];
+            std::memcpy(&rec[i * 16], &t, sizeof(BvhTri));
             const float *a = t.e1, *b = t.e2;
             const float cx = std::fmaf(a[1], b[2], -(a[2] * b[1])), cy = std::fmaf(a[2], b[0], -(a[0] * b[2])), cz = std::fmaf(a[0], b[1], -(a[1] * b[0]));
             const float inv = 1.0f / std::sqrt(std::fmaf(cz, cz, std::fmaf(cy, cy, cx * cx)));
-            ts[i * 4 + 0] = cx * inv; ts[i * 4 + 1] = cy * inv; ts[i * 4 + 2] = cz * inv;
-            std::memcpy(&ts[i * 4 + 3], &t.mat, 4);
+            rec[i * 16 + 12] = cx * inv; rec[i * 16 + 13] = cy * inv; rec[i * 16 + 14] = cz * inv;
+            std::memcpy(&rec[i * 16 + 15], &t.mat, 4);
         }
-        if (!ts.empty()) HIP_TRY(c, hipMemcpy(s->d_tri_shade.p, ts.data(), ts.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (!rec.empty()) HIP_TRY(c, hipMemcpy(s->d_tris.p, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     HIP_TRY(c, s->d_spheres.ensure(ns));
     HIP_TRY(c, s->d_sph_mat.ensure(ns));
     HIP_TRY(c, s->d_mats.ensure((size_t)nm * 3));
     if (s->node_bytes()) HIP_TRY(c, hipMemcpy(s->d_nodes.p, s->node_data(), s->node_bytes(), hipMemcpyHostToDevice));
-    if (!s->bvh.tris.empty()) HIP_TRY(c, hipMemcpy(s->d_tris.p, s->bvh.tris.data(), s->bvh.tris.size() * sizeof(BvhTri), hipMemcpyHostToDevice));
     if (ns) {
         HIP_TRY(c, hipMemcpy(s->d_spheres.p, s->spheres.data(), (size_t)ns * 16, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(s->d_sph_mat.p, s->sph_mat.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
@@ -359,7 +362,7 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     if (nm) HIP_TRY(c, hipMemcpy(s->d_mats.p, s->mats.data(), (size_t)nm * sizeof(pt_material), hipMemcpyHostToDevice));
 
     DeviceScene &d = s->ds;
-    d.nodes = s->d_nodes.p; d.tris = s->d_tris.p; d.tri_shade = s->d_tri_shade.p; d.spheres = s->d_spheres.p; d.sph_mat = s->d_sph_mat.p; d.mats = s->d_mats.p;
+    d.nodes = s->d_nodes.p; d.tris = s->d_tris.p; d.spheres = s->d_spheres.p; d.sph_mat = s->d_sph_mat.p; d.mats = s->d_mats.p;
     d.n_nodes = s->bvh.n_nodes; d.n_tris = nt; d.n_spheres = ns; d.n_mats = nm;
     for (int k = 0; k < 3; ++k) d.sky[k] = s->sky[k];
     d.bvh_width = bvh_width;
@@ -556,7 +559,8 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             const int shade_mode = s->has_specular ? 2 : 0;
             const bool fused = !split_kernels && !use_packed;
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
-            HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, use_packed ? packed_chunk : 0u, fused ? shade_mode : -1, compact));
+            HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, use_packed ? packed_chunk : 0u, fused ? shade_mode : -1, compact,
+                                     probing ? 1u : c->bounces)); // the probe compares per-ray rates of single iterations
             if (profile) HIP_TRY(c, hipEventRecord(e1, L.stream));
             if (!fused && !bucket_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, it, L.bound, shade_mode, compact));
             else if (!fused) {

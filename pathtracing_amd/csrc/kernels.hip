@@ -168,20 +168,39 @@ PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, floa
 // ------------------------------------------------------------------------------------------------
 // One path vertex (docs/SPEC.md §5): emission / sky, BSDF sample, throughput, Russian roulette, and in-place
 // regeneration of the stream's next camera sample when the path ends. (o, d, t, ref) = the ray and its closest hit.
-// Returns true when the slot holds a ray for the next iteration (its state has been written back).
+// Works on the registers in `r`; returns true when `r` holds a ray for the next bounce.
 //   SHADE_QUEUE   : Lambert and misses; a specular hit sets `defer` to its bucket and leaves the state untouched
 //   SHADE_BUCKETS : the hit's kind is `b` (wave-uniform)
 //   SHADE_INLINE  : every kind, by a divergent branch
 enum ShadeMode { SHADE_NONE = -1, SHADE_QUEUE = 0, SHADE_BUCKETS = 1, SHADE_INLINE = 2 };
+// The path state of a slot, held in registers between path_load and path_store (one bounce in k_shade, several in k_extend).
+struct PathRegs {
+    V3 o, d, T;                 // ray, throughput
+    uint32_t key, sample, depth; // RNG key of the path, sample index, vertices so far
+};
+PT_DEV void path_load(const PathState &ps, uint32_t slot, PathRegs &r)
+{
+    const float4 O = ps.ray_o[slot], D = ps.ray_d[slot], TK = ps.thr[slot];
+    const uint32_t sdv = ps.sd[slot];
+    r.o = xyz(O); r.d = xyz(D); r.T = xyz(TK);
+    r.key = __float_as_uint(TK.w); r.sample = sdv >> 8; r.depth = sdv & 255u;
+}
+PT_DEV void path_store(const PathState &ps, uint32_t slot, const PathRegs &r)
+{
+    ps.ray_o[slot] = make_float4(r.o.x, r.o.y, r.o.z, 0.f);
+    ps.ray_d[slot] = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
+    ps.thr[slot] = make_float4(r.T.x, r.T.y, r.T.z, __uint_as_float(r.key));
+    ps.sd[slot] = (r.sample << 8) | r.depth;
+}
+
 template <int MODE>
-PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t slot, V3 o, V3 d, float t, uint32_t ref,
+PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t slot, PathRegs &r, float t, uint32_t ref,
                       uint32_t b, uint32_t &defer)
 {
-    const float4 TK = ps.thr[slot];
-    const uint32_t sdv = ps.sd[slot];
-    V3 T = xyz(TK);
-    uint32_t key = __float_as_uint(TK.w), sample = sdv >> 8, depth = (sdv & 255u) + 1u;
-    float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+    V3 &o = r.o, &d = r.d, &T = r.T;
+    uint32_t &key = r.key, &sample = r.sample;
+    uint32_t depth = r.depth + 1u;
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f); // the slot's radiance sum | path count: read on first use, written back below
     bool touched = false, term = false, alive = false;
     auto add = [&](V3 L) {
         if (!touched) { A = ps.acc[slot]; touched = true; }
@@ -196,7 +215,8 @@ PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FramePar
         V3 ng;
         uint32_t mat;
         if (ref < sc.n_tris) {
-            const float4 ts = sc.tri_shade[ref]; // normalize(cross(e1,e2)) precomputed at commit, bit-identical
+            const float4 ts = sc.tris[(size_t)ref * 4 + 3]; // normalize(cross(e1,e2)) precomputed at commit, bit-identical; the
+                                                            // 4th row of the line k_extend fetched when it tested this triangle
             ng = xyz(ts);
             mat = __float_as_uint(ts.w);
         } else {
@@ -251,14 +271,8 @@ PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FramePar
             alive = true;
         }
     } else alive = true;
-
     if (touched) ps.acc[slot] = A;
-    if (alive) {
-        ps.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
-        ps.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
-        ps.thr[slot] = make_float4(T.x, T.y, T.z, __uint_as_float(key));
-        ps.sd[slot] = (sample << 8) | depth;
-    }
+    r.depth = depth;
     return alive;
 }
 
@@ -287,12 +301,20 @@ PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint
 //       others are still gathering nodes.
 // Counters are triple-buffered by iteration (cur = it % 3 is read, next is filled, the third is zeroed for the
 // iteration after), because a fused kernel fills `next` while other workgroups of the same launch are still starting.
+// Occupancy is worth more to this kernel than a few spills: it hides the latency of divergent node gathers with waves, and
+// unconstrained the fused variants take 84-89 VGPRs (5 waves/SIMD). Measured on the 1M-triangle Cornell box (Mrays/s):
+// 5 waves 9555, 6 waves 10326, 7 waves 10849 (SGPR spills only); the all-kinds variant spills 9 VGPRs at 7 and prefers 6.
+#ifndef PT_EXT_WAVES
+#define PT_EXT_WAVES(FUSE) ((FUSE) == SHADE_INLINE ? 6 : 7)
+#endif
 template <int L, bool COUNT, int FUSE>
-__global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint32_t compact)
+__global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(PT_EXT_WAVES(FUSE), PT_EXT_WAVES(FUSE)))) k_extend(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint32_t compact, uint32_t bounces)
 {
     const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u, czero = (it + 2u) % 3u;
     constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
     __shared__ int32_t s_stack[kStackLds * kExtBlock];
+    __shared__ uint32_t s_stash[(FUSE != SHADE_NONE ? 5 : 1) * kExtBlock];
+    volatile uint32_t *stash = s_stash; // volatile: the values must really leave the registers
     const uint32_t shard = blockIdx.y + ps.shard_base;
     const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)];
     const uint32_t tid = threadIdx.x;
@@ -300,8 +322,10 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
     if (gid == 0) {
         ps.counters[cnt_ext_index(czero, shard)] = 0u;         // the queue after next
         ps.counters[cnt_alive_index(czero, shard)] = 0u;
-        unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
-        *rays += ps.counters[cnt_alive_index(ccur, shard)];    // only this thread ever touches rays[shard]
+        if (FUSE == SHADE_NONE) { // one ray per alive entry; the fused kernel counts what it traces, per wavefront
+            unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
+            *rays += ps.counters[cnt_alive_index(ccur, shard)];
+        }
     }
     if (blockIdx.x * kExtBlock >= n) return;
     const size_t qbase = (size_t)shard * ps.shard_cap;
@@ -309,13 +333,30 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
     const bool active = slot != kInvalidSlot;                  // holes: paths that ended since the queue was last compacted
     const size_t uid = qbase + gid;                            // unique per thread of this launch
 
-    Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
     unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0;
-    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
-
+    PathRegs r;
+    r.o = v3(0.f, 0.f, 0.f); r.d = v3(0.f, 0.f, 1.f); r.T = v3(0.f, 0.f, 0.f); r.key = r.sample = r.depth = 0u;
     if (active) {
-        const float4 O = ps.ray_o[slot], D = ps.ray_d[slot];
-        o = xyz(O); d = xyz(D);
+        if (FUSE == SHADE_NONE) { r.o = xyz(ps.ray_o[slot]); r.d = xyz(ps.ray_d[slot]); }
+        else path_load(ps, slot, r);
+    }
+    bool alive = active;
+    uint32_t wave_rays = 0;
+    // FUSE: up to `bounces` path vertices per launch with the path state in registers (a terminated path continues with
+    // its stream's next camera ray, so most lanes stay busy); the state goes back to memory once, at the end.
+    const uint32_t n_bounces = FUSE == SHADE_NONE ? 1u : bounces;
+    for (uint32_t bounce = 0; bounce < n_bounces; ++bounce) {
+    const uint64_t alive_mask = __ballot(alive);
+    if (alive_mask == 0) break;
+    wave_rays += (uint32_t)__popcll(alive_mask);
+    if (alive) {
+        const V3 o = r.o, d = r.d;
+        Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
+        if (FUSE != SHADE_NONE) { // park what traversal does not need in LDS: 5 VGPRs less while the wave gathers nodes
+            stash[0 * kExtBlock + tid] = __float_as_uint(r.T.x); stash[1 * kExtBlock + tid] = __float_as_uint(r.T.y);
+            stash[2 * kExtBlock + tid] = __float_as_uint(r.T.z); stash[3 * kExtBlock + tid] = r.key;
+            stash[4 * kExtBlock + tid] = (r.sample << 8) | r.depth;
+        }
 
         for (uint32_t j = 0; j < sc.n_spheres; ++j) { // uniform index => scalar loads
             sphere_test(sc.spheres[j], sc.n_tris + j, o, d, h);
@@ -347,7 +388,7 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
             // one fetch for both kinds of step: 4 rows from the node, or from the first triangle of the leaf
             const bool inner = cur >= 0;
             const uint32_t enc = (uint32_t)~cur, first = enc >> 3, more = enc & 7u; // leaf: `more` triangles after this one
-            const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 3;
+            const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 4;
             const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
             if (inner) {
                 uint32_t key[4];
@@ -366,17 +407,26 @@ __global__ void __launch_bounds__(kExtBlock) k_extend(DeviceScene sc, PathState 
         }
 
         if (FUSE == SHADE_NONE) ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref)); // k_shade walks the same queue in the same order
-        if (COUNT) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
-            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
-            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);
+        else {
+            r.T = v3(__uint_as_float(stash[0 * kExtBlock + tid]), __uint_as_float(stash[1 * kExtBlock + tid]), __uint_as_float(stash[2 * kExtBlock + tid]));
+            r.key = stash[3 * kExtBlock + tid];
+            const uint32_t sdv = stash[4 * kExtBlock + tid];
+            r.sample = sdv >> 8; r.depth = sdv & 255u;
+            uint32_t defer = 0u;
+            alive = shade_one<FUSE>(sc, ps, fp, slot, r, h.t, h.ref, B_LAMBERT, defer);
         }
     }
+    }
+    if (COUNT && active) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
+        atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
+        atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);
+    }
     if (FUSE != SHADE_NONE) {
-        bool alive = false;
-        uint32_t defer = 0u;
-        if (active) alive = shade_one<FUSE>(sc, ps, fp, slot, o, d, h.t, h.ref, B_LAMBERT, defer);
+        if (alive) path_store(ps, slot, r);
         queue_next(ps, shard, cnext, ps.q_ext[parity ^ 1u] + qbase, gid, n, alive, slot, compact != 0u);
+        if (wave_rays && lane_id() == 0u)
+            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard)), (unsigned long long)wave_rays);
     }
 }
 
@@ -476,7 +526,7 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
             if (cur != PT_BVH_EMPTY) {
                 const bool inner = cur >= 0;
                 const uint32_t enc = (uint32_t)~cur, first = enc >> 3, more = enc & 7u;
-                const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 3;
+                const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 4;
                 const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
                 if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; }
                 else if (inner) {
@@ -545,8 +595,10 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
 
     if (active) {
         const float2 hr = ps.hit[slot];
-        const float4 O = ps.ray_o[slot], D = ps.ray_d[slot];
-        alive = shade_one<MODE>(sc, ps, fp, slot, xyz(O), xyz(D), hr.x, __float_as_uint(hr.y), b, defer);
+        PathRegs r;
+        path_load(ps, slot, r);
+        alive = shade_one<MODE>(sc, ps, fp, slot, r, hr.x, __float_as_uint(hr.y), b, defer);
+        if (alive) path_store(ps, slot, r); // a deferred hit stores nothing: its state stays as k_extend left it
     }
     queue_next(ps, shard, cnext, ps.q_ext[parity ^ 1u] + qbase, gid, total, alive, slot, SPEC || compact);
     if (MODE == SHADE_QUEUE) {
@@ -612,17 +664,18 @@ hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState
 
 template <int L, bool C>
 static void extend_lc(hipStream_t s, dim3 grid, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t chunk, int fuse,
-                      uint32_t cm)
+                      uint32_t cm, uint32_t bounces)
 {
     if (chunk) hipLaunchKernelGGL((k_extend_packed<L, C>), grid, dim3(64), 0, s, sc, ps, it, chunk);
-    else if (fuse == SHADE_QUEUE) hipLaunchKernelGGL((k_extend<L, C, SHADE_QUEUE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm);
-    else if (fuse == SHADE_INLINE) hipLaunchKernelGGL((k_extend<L, C, SHADE_INLINE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm);
-    else hipLaunchKernelGGL((k_extend<L, C, SHADE_NONE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm);
+    else if (fuse == SHADE_QUEUE) hipLaunchKernelGGL((k_extend<L, C, SHADE_QUEUE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm, bounces);
+    else if (fuse == SHADE_INLINE) hipLaunchKernelGGL((k_extend<L, C, SHADE_INLINE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm, bounces);
+    else hipLaunchKernelGGL((k_extend<L, C, SHADE_NONE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm, bounces);
 }
 
 hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t shard_bound, bool count,
-                         uint32_t packed_chunk, int fuse, bool compact)
+                         uint32_t packed_chunk, int fuse, bool compact, uint32_t bounces)
 {
+    const uint32_t nb = bounces ? bounces : 1u;
     // packed_chunk >= 64: rays per wavefront of the lane-packing kernel (PT_FLAG_EXTEND_PACKED); 0: one ray per lane.
     // Measured on MI355X: packing raises lane utilisation but is slower at every chunk size, because the
     // kernel is bound by outstanding divergent node fetches and fewer waves means fewer of them; it stays selectable.
@@ -630,9 +683,9 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
     const dim3 grid(shard_bound ? (shard_bound + per_block - 1) / per_block : 1u, ps.shard_count);
     const uint32_t cm = compact ? 1u : 0u;
     switch (sc.bvh_width) {
-    case PT_BVH_WIDTH_2:  count ? extend_lc<PT_BVH_WIDTH_2, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm) : extend_lc<PT_BVH_WIDTH_2, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm); break;
-    case PT_BVH_WIDTH_4:  count ? extend_lc<PT_BVH_WIDTH_4, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm) : extend_lc<PT_BVH_WIDTH_4, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm); break;
-    case PT_BVH_WIDTH_4Q: count ? extend_lc<PT_BVH_WIDTH_4Q, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm) : extend_lc<PT_BVH_WIDTH_4Q, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm); break;
+    case PT_BVH_WIDTH_2:  count ? extend_lc<PT_BVH_WIDTH_2, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_2, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
+    case PT_BVH_WIDTH_4:  count ? extend_lc<PT_BVH_WIDTH_4, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_4, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
+    case PT_BVH_WIDTH_4Q: count ? extend_lc<PT_BVH_WIDTH_4Q, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_4Q, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

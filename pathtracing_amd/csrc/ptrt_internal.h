@@ -11,7 +11,7 @@ constexpr uint32_t kTile = 1u << kTileShift;
 constexpr uint32_t kTilePixels = kTile * kTile;
 constexpr uint32_t kBlock = 256;                   // threads per workgroup = 4 wavefronts
 #ifndef PT_STACK_LDS
-#define PT_STACK_LDS 24
+#define PT_STACK_LDS 12
 #endif
 #ifndef PT_EXT_BLOCK
 #define PT_EXT_BLOCK 64
@@ -52,8 +52,8 @@ inline __host__ __device__ uint32_t cnt_rays_index(uint32_t shard) { return kCnt
 
 struct DeviceScene {
     const float4 *nodes;   // BVH-N: node i slot c = rows (i*N + c)*2 + {0: lo.xyz|ref, 1: hi.xyz|0}
-    const float4 *tris;    // 3 rows per triangle: v0|orig_id, e1|material, e2|0
-    const float4 *tri_shade; // per triangle (blob order): geometric normal normalize(cross(e1,e2)) | material
+    const float4 *tris;    // 4 rows (one 64-B line) per triangle, blob order: v0|orig_id, e1|material, e2|0, then the
+                           // shading row normalize(cross(e1,e2))|material
     const float4 *spheres; // cx,cy,cz,r
     const uint32_t *sph_mat;
     const float4 *mats;    // 3 rows per material (48 B pt_material)
@@ -97,8 +97,9 @@ hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState
 // `it` = iteration index of the wavefront loop: queues alternate by it & 1, queue counters rotate by it % 3.
 // fuse: -1 = extend only (k_shade follows); 0 / 2 = k_extend also shades (Lambert-only / all kinds) and queues the next
 // iteration, honouring `compact` like launch_shade. Ignored (treated as -1) by the lane-packing kernel.
+// bounces (fused only): path vertices a lane advances per launch with its path state in registers.
 hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t shard_bound, bool count,
-                         uint32_t packed_chunk, int fuse, bool compact);
+                         uint32_t packed_chunk, int fuse, bool compact, uint32_t bounces);
 // mode: 0 = queue order, specular kinds deferred to buckets; 1 = the specular buckets; 2 = queue order, everything shaded in place
 // compact: 1 = survivors are appended densely to the next queue (ballot + one returning atomic per wavefront);
 //          0 = every lane writes its own position of the next queue (slot or kInvalidSlot): no returning atomics, and the

@@ -336,6 +336,29 @@ def test_queue_compaction_policy_is_invisible(P, pto, monkeypatch, flags):
     assert frames[0][2] == 0 and frames[1][2] == frames[1][3] and 0 < frames[2][2] < frames[2][3]
 
 
+def test_bounces_per_launch_is_invisible(P, pto, monkeypatch):
+    """PTRT_BOUNCES: the fused kernel advances a path by 1, 3 or 16 vertices per launch with its state in registers
+    (kernels.hip k_extend). Same arithmetic per vertex, so frame, ray count and visit counters stay the oracle's."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 4, 160, 120)
+    p = P.make_params(160, 120, spp=5, max_depth=9, streams=2, flags=P.native.PT_FLAG_COUNT_VISITS)
+    got = []
+    for b in ("1", "3", "16"):
+        monkeypatch.setenv("PTRT_BOUNCES", b)
+        r = P.Renderer(P.Window(160, 120)); r.Init()
+        try:
+            r.SetScene(sd, 0); r.Params = p
+            st = r.Render(0.0)
+            got.append((st.rays, st.node_visits, st.tri_tests, st.sphere_tests, r.ReadFramebuffer(), st.iterations))
+            if b == "3":
+                info = r.BvhInfo()
+                ref, ost = pto.render(pto.Scene(sd, (info.width,) + r.BvhRead()), p)
+                assert (ost.rays, ost.node_visits, ost.tri_tests, ost.sphere_tests) == got[-1][:4] and np.array_equal(got[-1][4], ref)
+        finally:
+            r.Dispose()
+    assert all(g[:4] == got[0][:4] and np.array_equal(g[4], got[0][4]) for g in got)
+    assert got[0][5] > got[1][5] > got[2][5]  # fewer launches
+
+
 def test_image_output(P, pto, renderer, tmp_path):
     """PPM carries the reference's R8G8B8A8Unorm quantisation (Renderer.cs:124), PFM the linear floats."""
     renderer.Params = P.make_params(97, 41, mode=P.native.PT_REFERENCE_SPHERE)
