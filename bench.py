@@ -10,7 +10,8 @@ scene, and the only data-path collective is ONE gather of per-rank tile radiance
 Total work per frame is fixed => "scaling": "strong". value = rays traced by all ranks / wall time (max over ranks).
 
 Extra objects on the JSON line (task §④):
-  roofline     : dominant kernel = the extend kernel (BVH traversal + intersection). achieved = algorithmic bytes per
+  roofline     : dominant kernel = the extend kernel (BVH traversal + intersection, and in the default fused pipeline also
+                 shading, up to 4 path vertices per launch). achieved = algorithmic bytes per
                  launch (B_ray x rays per launch) / mean launch duration, measured live with HIP events on
                  the library's own stream (pt_stats.extend_ms, PT_FLAG_PROFILE_KERNELS) in a separate, untimed frame.
                  traffic = rocprofv3 FETCH_SIZE(x2, gfx950)+WRITE_SIZE per launch from the committed PMC passes
@@ -170,9 +171,17 @@ def main():
         n_tris_ray = sc.tri_tests / sc.rays
         n_sph_ray = sc.sphere_tests / sc.rays
         node_bytes = 64.0 if info.width in (2, 68) else 128.0
-        # algorithmic bytes the extend kernel must move per ray:
-        #   queue slot 4 + ray 32 (two float4) + hit record 8, + node / triangle / sphere bytes of the visits it makes
-        b_ray = 44.0 + node_bytes * n_nodes_ray + 48.0 * n_tris_ray + 16.0 * n_sph_ray
+        fused = sp.shade_ms < 0.05 * sp.extend_ms  # the default pipeline: k_extend shades its own hits, several bounces per launch
+        # algorithmic bytes the dominant kernel must move per ray:
+        #   traversal : node / triangle / sphere bytes of the visits it makes
+        #   fused     : + path state once per launch and alive path (queue 4 + ray, throughput|key, sample|depth 52, read and
+        #               written = 112 B; pt_stats.reserved[2] counts those) + the 32-B accumulator update per finished path
+        #   split     : + queue slot 4 + ray 32 + hit record 8 per ray (k_shade's traffic belongs to the other kernel)
+        b_trav = node_bytes * n_nodes_ray + 48.0 * n_tris_ray + 16.0 * n_sph_ray
+        if fused:
+            b_ray = b_trav + 112.0 * int(sp.reserved[2]) / sp.rays + 32.0 * sp.paths / sp.rays
+        else:
+            b_ray = b_trav + 44.0
         launches = sp.extend_launches
         achieved = b_ray * sp.rays / (sp.extend_ms * 1e-3) / 1e9
         traffic = None
@@ -183,10 +192,11 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out["roofline"] = {
-            "bound": "hbm", "kernel": f"{kernel_choice}<{info.width}>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": f"{kernel_choice}<{info.width}{', fused shade' if fused else ''}>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable_6290": round(achieved / HBM_ACHIEVABLE_GBS, 4),
             "traffic": traffic,
-            "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(n_nodes_ray, 2), "tris_per_ray": round(n_tris_ray, 2),
+            "bytes_per_ray": round(b_ray, 1), "traversal_bytes_per_ray": round(b_trav, 1),
+            "path_states_per_ray": round(int(sp.reserved[2]) / sp.rays, 3), "nodes_per_ray": round(n_nodes_ray, 2), "tris_per_ray": round(n_tris_ray, 2),
             "spheres_per_ray": round(n_sph_ray, 2), "launches": launches, "mean_launch_ms": round(sp.extend_ms / launches, 4),
             "bytes_per_launch": round(b_ray * sp.rays / launches), "rays_per_launch": round(sp.rays / launches, 1),
             "extend_ms": round(sp.extend_ms, 2), "shade_ms": round(sp.shade_ms, 2), "frame_ms_profiled": round(sp.gpu_ms, 2),

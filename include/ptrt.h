@@ -113,13 +113,16 @@ typedef struct {
     uint64_t rays;          /* ray-scene intersection queries = path segments (the benchmark's unit) */
     uint64_t paths;
     uint64_t node_visits, tri_tests, sphere_tests; /* only with PT_FLAG_COUNT_VISITS, else 0 */
-    uint32_t iterations;    /* wavefront iterations (extend+shade rounds) */
+    uint32_t iterations;    /* wavefront iterations = launches of the extend kernel; the default (fused) kernel advances every
+                               path by up to PTRT_BOUNCES (4) vertices per iteration */
     uint32_t extend_launches;
     double gpu_ms;          /* hipEvent start->stop around all kernels of the frame */
-    double extend_ms;       /* sum of extend-kernel durations (PT_FLAG_PROFILE_KERNELS) */
-    double shade_ms;        /* sum of shade-kernel durations  (PT_FLAG_PROFILE_KERNELS) */
+    double extend_ms;       /* sum of extend-kernel durations (PT_FLAG_PROFILE_KERNELS); includes shading when fused */
+    double shade_ms;        /* sum of shade-kernel durations  (PT_FLAG_PROFILE_KERNELS); ~0 when fused */
     double other_ms;        /* generate / resolve kernels */
-    uint64_t reserved[4];
+    uint64_t reserved[4];   /* diagnostics: [0] extend kernel in use (1 one ray per lane, 2 lane-packing, 0 unprobed),
+                               [1] iterations that re-packed their queues, [2] path states loaded+stored by the loop
+                               (sum over iterations of the paths alive at its start), [3] 0 */
 } pt_stats;
 
 typedef struct {

@@ -69,8 +69,12 @@ struct pt_context {
                                                 // the default stays 1 so that a launch timed by HIP events, by rocprofv3 and
                                                 // in the benchmark frame is one and the same thing (kernels alone on the GPU)
     uint32_t bounces = 4;                       // PTRT_BOUNCES (1..64): path vertices per launch of the fused kernel (state in registers)
-    double compact_below = 0.75;               // PTRT_COMPACT overrides: k_shade re-packs a loop's queues once alive/length drops
-                                                // below this (>1 = every iteration, 0 = never); otherwise queues are carried in place
+    double compact_below = 0.9;                // PTRT_COMPACT overrides: a shard re-packs its queue in an iteration that starts with
+                                                // alive/length below this (>1 = every iteration, 0 = never); else carried in place.
+                                                // Measured (1M-tri Cornell): 1080p/64spp 0.75: 10786, 0.9: 11190, always: 11354 Mrays/s;
+                                                // 4K/1024spp 0.9: 12471, always: 11430 — re-packing mixes wavefronts, long frames feel it
+    uint32_t finish_below = 4096;             // PTRT_FINISH overrides: a shard with no more alive paths than this runs them to
+                                                // their end in one launch of the fused kernel (0 = never)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_probe[4] = {}; // brackets of the two probe iterations that pick the extend kernel
     std::vector<hipEvent_t> ev_pool;
@@ -181,6 +185,7 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
     bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * (kFinalOffset + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
     if (const char *e = getenv("PTRT_GROUPS")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4) c->groups = (uint32_t)g; }
     if (const char *e = getenv("PTRT_BOUNCES")) { const int b = atoi(e); if (b >= 1 && b <= 64) c->bounces = (uint32_t)b; }
+    if (const char *e = getenv("PTRT_FINISH")) { const long v = atol(e); if (v >= 0 && v <= (1l << 30)) c->finish_below = (uint32_t)v; }
     if (const char *e = getenv("PTRT_COMPACT")) { const double v = atof(e); if (v >= 0.0 && v <= 2.0) c->compact_below = v; }
     for (uint32_t g = 0; ok && g < kMaxGroups; ++g) {
         ok = hipStreamCreateWithFlags(&c->group_stream[g], hipStreamNonBlocking) == hipSuccess &&
@@ -482,6 +487,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     for (uint32_t b = 0; b < B_COUNT; ++b) ps.q_bucket[b] = c->q_b[b].p;
     ps.counters = c->counters.p; ps.stack_ovf = c->stack_ovf.p; ps.stack_ovf_entries = ovf; ps.n_slots = n_slots; ps.shard_cap = shard_cap;
     ps.shard_base = 0; ps.shard_count = kShards;
+    ps.compact_below = (float)c->compact_below; ps.finish_below = c->finish_below;
 
     FrameParams fp{};
     fp.width = p->width; fp.height = p->height; fp.spp = p->spp; fp.max_depth = p->max_depth; fp.rr_start = p->rr_start;
@@ -515,15 +521,16 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     const uint32_t n_loops = (profile || count) ? 1u : c->groups; // per-kernel timing and visit counting want kernels alone on the GPU
     const uint32_t per_group = kShards / n_loops;
     //
-    // Queues are carried over IN PLACE from one iteration to the next (k_shade, compact = 0): a lane writes its own queue
-    // position, dead paths leave holes, and lane <-> slot stays the generation order, so the slot-indexed state keeps
-    // its coalescing and k_shade needs no returning atomic. Only when the lagged alive/length ratio of a loop falls
-    // below `compact_below` does one k_shade re-pack the survivors (ballot + atomic append), which shortens the launches.
-    struct Loop { hipStream_t stream; uint32_t base, bound, iters; bool done, compact_next; int64_t last_compact; };
+    // Queues are carried over IN PLACE from one iteration to the next: a lane writes its own queue position, dead paths
+    // leave holes, and lane <-> slot stays the generation order, so the slot-indexed state keeps its coalescing and no
+    // returning atomic is needed. A shard re-packs its survivors (ballot + atomic append) in the iteration in which its
+    // alive/length ratio is below `compact_below`, and runs its last `finish_below` paths to their end in one launch;
+    // both are decided by the kernels from the shard's counters, the host only sizes grids and notices the end.
+    struct Loop { hipStream_t stream; uint32_t base, bound, iters; bool done; };
     Loop loops[kMaxGroups];
     HIP_TRY(c, hipEventRecord(c->ev_fork, q));
     for (uint32_t g = 0; g < n_loops; ++g) {
-        loops[g] = Loop{ n_loops == 1 ? q : c->group_stream[g], g * per_group, shard_cap, 0u, false, false, -1 }; // no shard's queue can outgrow its slots
+        loops[g] = Loop{ n_loops == 1 ? q : c->group_stream[g], g * per_group, shard_cap, 0u, false }; // no shard's queue can outgrow its slots
         if (loops[g].stream != q) HIP_TRY(c, hipStreamWaitEvent(loops[g].stream, c->ev_fork, 0));
     }
     const uint64_t max_iters = (uint64_t)p->spp * p->max_depth + kLag + 2;
@@ -535,7 +542,9 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     // traversals (1M-triangle soup) gain ~1.5x from packing, shallow ones (walls of a box) lose ~8 %, and nothing static tells them apart.
     pt_scene *scene_mut = const_cast<pt_scene *>(s);
     uint32_t ext_choice = forced_choice ? forced_choice : scene_mut->ext_choice; // 0 = still probing, 1 = simple, 2 = packed
-    uint64_t probe_n[2] = { 0, 0 }, n_compactions = 0;
+    uint64_t probe_n[2] = { 0, 0 }, slot_launches = 0;
+    const bool trace = profile && getenv("PTRT_TRACE") != nullptr; // developer aid: per-iteration table on stderr
+    std::vector<uint64_t> trace_alive, trace_rays;
     for (uint32_t live = n_loops; live > 0;) {
         for (uint32_t g = 0; g < n_loops; ++g) {
             Loop &L = loops[g];
@@ -544,6 +553,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             const uint32_t it = L.iters;
             PathState pg = ps;
             pg.shard_base = L.base; pg.shard_count = per_group;
+            if (ext_choice == 0u) pg.finish_below = 0u; // while the extend kernel is still being probed, iterations stay comparable
             hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
             if (profile) {
                 e0 = pool_event(c, nev++); e1 = pool_event(c, nev++); e2 = pool_event(c, nev++);
@@ -552,15 +562,14 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             }
             const bool probing = g == 0u && ext_choice == 0u && (L.iters == 2u || L.iters == 3u);
             const bool use_packed = ext_choice == 2u || (probing && L.iters == 3u);
-            const bool compact = L.compact_next || c->compact_below > 1.0 || bucket_specular; // buckets re-append: no fixed positions
-            if (compact) { L.compact_next = false; L.last_compact = (int64_t)L.iters; ++n_compactions; }
+            const bool compact = bucket_specular; // forced: buckets re-append, there are no fixed positions
             // One kernel per iteration by default: the one-ray-per-lane k_extend shades its own hits (mode 0: Lambert-only
             // scene, lean code; 2: all kinds). The lane-packing kernel and the bucketed pipeline keep k_shade as a second kernel.
             const int shade_mode = s->has_specular ? 2 : 0;
             const bool fused = !split_kernels && !use_packed;
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
             HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, use_packed ? packed_chunk : 0u, fused ? shade_mode : -1, compact,
-                                     probing ? 1u : c->bounces)); // the probe compares per-ray rates of single iterations
+                                     c->bounces));
             if (profile) HIP_TRY(c, hipEventRecord(e1, L.stream));
             if (!fused && !bucket_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, it, L.bound, shade_mode, compact));
             else if (!fused) {
@@ -581,18 +590,22 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
                 HIP_TRY(c, hipEventSynchronize(c->ev_lag[g][old]));
                 const uint32_t *h_old = c->h_counts + ((size_t)g * kLag + old) * kRingWords;
                 uint32_t mx = 0;
-                uint64_t total = 0, len_sum = 0; // word 0 of a shard's line = queue length (holes included), word 1 = alive entries
+                // a shard's line: word 0 = queue length (holes included), word 1 = alive entries, words 2-3 = rays the iteration traced
+                uint64_t total = 0, traced = 0;
                 for (uint32_t sh = 0; sh < per_group; ++sh) {
                     mx = std::max(mx, h_old[sh * kCounterStride]);
-                    len_sum += h_old[sh * kCounterStride];
                     total += h_old[sh * kCounterStride + 1];
+                    traced += (uint64_t)h_old[sh * kCounterStride + 2] | ((uint64_t)h_old[sh * kCounterStride + 3] << 32);
                 }
                 L.bound = mx;
+                const uint32_t old_iter = L.iters - kLag; // iteration old_iter traced `traced` rays and left `total` paths alive
+                if (trace) {
+                    trace_alive.resize(std::max<size_t>(trace_alive.size(), old_iter + 1), 0); trace_rays.resize(trace_alive.size(), 0);
+                    trace_alive[old_iter] += total; trace_rays[old_iter] += traced;
+                }
+                slot_launches += total; // = paths alive at the start of iteration old_iter + 1 (those read after the loop ended are all 0)
                 if (total == 0) { L.done = true; --live; }
-                const uint32_t old_iter = L.iters - kLag; // `total` = rays of this group's iteration old_iter + 1
-                // lengths only change when k_shade compacts, so a ratio read after the last compaction is still current
-                if ((int64_t)old_iter >= L.last_compact && (double)total < c->compact_below * (double)len_sum) L.compact_next = true;
-                if (g == 0u && ext_choice == 0u && (old_iter == 1u || old_iter == 2u)) probe_n[old_iter - 1u] = total;
+                if (g == 0u && ext_choice == 0u && (old_iter == 2u || old_iter == 3u)) probe_n[old_iter - 2u] = traced;
                 if (g == 0u && ext_choice == 0u && old_iter == 3u) { // iterations 2 and 3 (and their events) are complete by now
                     float ms_simple = 0.f, ms_packed = 0.f;
                     HIP_TRY(c, hipEventElapsedTime(&ms_simple, c->ev_probe[0], c->ev_probe[1]));
@@ -629,7 +642,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     out.node_visits = u64_at(kCntNodes); out.tri_tests = u64_at(kCntTris); out.sphere_tests = u64_at(kCntSph);
     out.iterations = iters; out.extend_launches = iters;
     out.reserved[0] = ext_choice; // extend kernel in use at frame end: 1 = one ray per lane, 2 = lane-packing, 0 = frame too short to probe
-    out.reserved[1] = n_compactions; // k_shade launches that re-packed their queues (the others carried them over in place)
+    out.reserved[1] = hc[kCntCompactions]; // (shard, iteration) pairs that re-packed their queue (the others carried it over in place)
     {   // paths = owned in-image pixels x spp
         uint64_t px = 0;
         for (uint32_t t = p->rank; t < lay.n_tiles; t += nranks) {
@@ -638,6 +651,9 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             px += (uint64_t)w * h;
         }
         out.paths = px * p->spp;
+        // path states read + written by the wavefront loop = sum over launches of the paths alive at launch start
+        // (iteration 0 starts every (pixel, stream) pair that has a sample)
+        out.reserved[2] = slot_launches + px * std::min(streams, p->spp);
     }
     if (profile) {
         for (size_t i = 0; i + 2 < nev; i += 3) { // three events per iteration: before extend, between, after shade
@@ -645,6 +661,9 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             HIP_TRY(c, hipEventElapsedTime(&a, c->ev_pool[i], c->ev_pool[i + 1]));
             HIP_TRY(c, hipEventElapsedTime(&b, c->ev_pool[i + 1], c->ev_pool[i + 2]));
             out.extend_ms += a; out.shade_ms += b;
+            if (trace) fprintf(stderr, "ptrt: iteration %3zu  rays %10llu  alive after %10llu  extend %8.3f ms  shade %8.3f ms\n", i / 3,
+                               (unsigned long long)(i / 3 < trace_rays.size() ? trace_rays[i / 3] : 0),
+                               (unsigned long long)(i / 3 < trace_alive.size() ? trace_alive[i / 3] : 0), a, b);
         }
         out.other_ms = out.gpu_ms - out.extend_ms - out.shade_ms;
     }

@@ -279,6 +279,24 @@ PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FramePar
 // Hand a lane's surviving slot to the next iteration's extend queue (reached by all lanes of the workgroup).
 //   compact : append (ballot + one returning atomic per wavefront) -> dense queue, order scrambled by wavefront
 //   else    : write position `gid` of the next queue (slot or hole); the shard's length carries over
+// Ray accounting: the iteration that fills queue `c` counts the rays it traces in that queue's line (u64, words 2-3); the
+// next iteration's first thread folds the count into rays[shard] and clears the line that is two iterations ahead.
+PT_DEV unsigned long long *traced_counter(const PathState &ps, uint32_t c, uint32_t shard)
+{
+    return reinterpret_cast<unsigned long long *>(ps.counters + cnt_traced_index(c, shard));
+}
+PT_DEV void fold_traced(const PathState &ps, uint32_t shard, uint32_t it)
+{
+    *traced_counter(ps, (it + 2u) % 3u, shard) = 0ull;
+    *reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard)) += *traced_counter(ps, it % 3u, shard);
+}
+
+// Queue policy, from the shard's own counters so that every workgroup of a launch decides the same and without host lag.
+PT_DEV bool want_compact(const PathState &ps, uint32_t len, uint32_t n_alive, bool forced)
+{
+    return forced || (float)n_alive < ps.compact_below * (float)len;
+}
+
 PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint32_t *q_next, uint32_t gid, uint32_t total, bool alive,
                        uint32_t slot, bool compact)
 {
@@ -316,18 +334,19 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     __shared__ uint32_t s_stash[(FUSE != SHADE_NONE ? 5 : 1) * kExtBlock];
     volatile uint32_t *stash = s_stash; // volatile: the values must really leave the registers
     const uint32_t shard = blockIdx.y + ps.shard_base;
-    const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)];
+    const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)], n_alive = ps.counters[cnt_alive_index(ccur, shard)];
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * kExtBlock + tid;          // index inside the shard's queue
+    const bool do_compact = FUSE != SHADE_NONE && want_compact(ps, n, n_alive, compact != 0u);
     if (gid == 0) {
         ps.counters[cnt_ext_index(czero, shard)] = 0u;         // the queue after next
         ps.counters[cnt_alive_index(czero, shard)] = 0u;
-        if (FUSE == SHADE_NONE) { // one ray per alive entry; the fused kernel counts what it traces, per wavefront
-            unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
-            *rays += ps.counters[cnt_alive_index(ccur, shard)];
-        }
+        fold_traced(ps, shard, it);
+        if (FUSE == SHADE_NONE) *traced_counter(ps, cnext, shard) = n_alive; // one ray per alive entry; the fused kernel
+                                                                             // counts what it traces, per wavefront
+        if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
     }
-    if (blockIdx.x * kExtBlock >= n) return;
+    if (blockIdx.x * kExtBlock >= n || n_alive == 0u) return;
     const size_t qbase = (size_t)shard * ps.shard_cap;
     const uint32_t slot = gid < n ? ps.q_ext[parity][qbase + gid] : kInvalidSlot;
     const bool active = slot != kInvalidSlot;                  // holes: paths that ended since the queue was last compacted
@@ -344,7 +363,9 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     uint32_t wave_rays = 0;
     // FUSE: up to `bounces` path vertices per launch with the path state in registers (a terminated path continues with
     // its stream's next camera ray, so most lanes stay busy); the state goes back to memory once, at the end.
-    const uint32_t n_bounces = FUSE == SHADE_NONE ? 1u : bounces;
+    // Once few paths are left in the shard (the frame's tail) the launch runs them to their end instead: launches that
+    // small cost more in launch latency and host round trips than the lanes idling behind a wave's longest path.
+    const uint32_t n_bounces = FUSE == SHADE_NONE ? 1u : (n_alive <= ps.finish_below ? 0xFFFFFFFFu : bounces);
     for (uint32_t bounce = 0; bounce < n_bounces; ++bounce) {
     const uint64_t alive_mask = __ballot(alive);
     if (alive_mask == 0) break;
@@ -424,9 +445,8 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     }
     if (FUSE != SHADE_NONE) {
         if (alive) path_store(ps, slot, r);
-        queue_next(ps, shard, cnext, ps.q_ext[parity ^ 1u] + qbase, gid, n, alive, slot, compact != 0u);
-        if (wave_rays && lane_id() == 0u)
-            atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard)), (unsigned long long)wave_rays);
+        queue_next(ps, shard, cnext, ps.q_ext[parity ^ 1u] + qbase, gid, n, alive, slot, do_compact);
+        if (wave_rays && lane_id() == 0u) atomicAdd(traced_counter(ps, cnext, shard), (unsigned long long)wave_rays);
     }
 }
 
@@ -454,8 +474,8 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
     if (blockIdx.x == 0 && lane == 0) {
         ps.counters[cnt_ext_index(czero, shard)] = 0u;
         ps.counters[cnt_alive_index(czero, shard)] = 0u;
-        unsigned long long *rays = reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard));
-        *rays += ps.counters[cnt_alive_index(ccur, shard)];
+        fold_traced(ps, shard, it);
+        *traced_counter(ps, (it + 1u) % 3u, shard) = ps.counters[cnt_alive_index(ccur, shard)]; // one ray per alive entry
     }
     uint32_t next = blockIdx.x * chunk;                       // wave-uniform cursor into the shard's queue
     if (next >= n) return;
@@ -580,6 +600,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
         if (blockIdx.x == 0 && threadIdx.x < 2u) // the other parity's buckets were consumed by the previous k_shade<true>
             ps.counters[cnt_bucket_index(parity ^ 1u, B_METAL + threadIdx.x, shard)] = 0u;
     } else total = ps.counters[cnt_ext_index(ccur, shard)];
+    const uint32_t n_alive = ps.counters[cnt_alive_index(ccur, shard)];
+    const bool do_compact = SPEC || want_compact(ps, total, n_alive, compact != 0u);
+    if (!SPEC && do_compact && n_alive && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ps.counters[kCntCompactions], 1u);
     // SPEC: a small fixed grid strides over the (usually short, unknown-length) specular buckets, so an empty bucket
     // costs a few hundred trivial blocks instead of one per 256 queue slots. !SPEC: exactly one pass, grid sized by the host.
     for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
@@ -600,7 +623,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
         alive = shade_one<MODE>(sc, ps, fp, slot, r, hr.x, __float_as_uint(hr.y), b, defer);
         if (alive) path_store(ps, slot, r); // a deferred hit stores nothing: its state stays as k_extend left it
     }
-    queue_next(ps, shard, cnext, ps.q_ext[parity ^ 1u] + qbase, gid, total, alive, slot, SPEC || compact);
+    queue_next(ps, shard, cnext, ps.q_ext[parity ^ 1u] + qbase, gid, total, alive, slot, do_compact);
     if (MODE == SHADE_QUEUE) {
         wave_push(&ps.counters[cnt_bucket_index(parity, B_METAL, shard)], ps.q_bucket[B_METAL] + qbase, defer == B_METAL, slot);
         wave_push(&ps.counters[cnt_bucket_index(parity, B_DIELECTRIC, shard)], ps.q_bucket[B_DIELECTRIC] + qbase, defer == B_DIELECTRIC, slot);

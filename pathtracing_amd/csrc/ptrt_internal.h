@@ -37,6 +37,7 @@ constexpr uint32_t kCntRays = kCntBucket + 2 * B_COUNT * kShards * kCounterStrid
 constexpr uint32_t kCntGlobals = kCntRays + kShards * kCounterStride;
 constexpr uint32_t kCntError = kCntGlobals + 0;
 constexpr uint32_t kCntNodes = kCntGlobals + 2, kCntTris = kCntGlobals + 4, kCntSph = kCntGlobals + 6; // u64 each
+constexpr uint32_t kCntCompactions = kCntGlobals + 8; // (shard, iteration) pairs that re-packed their queue
 constexpr uint32_t kCntTotalWords = kCntGlobals + 16;
 
 // An extend queue has LEN entries of which ALIVE hold a slot; the rest are kInvalidSlot holes left by paths that ended
@@ -44,6 +45,8 @@ constexpr uint32_t kCntTotalWords = kCntGlobals + 16;
 constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
 inline __host__ __device__ uint32_t cnt_ext_index(uint32_t parity, uint32_t shard) { return kCntExt + (parity * kShards + shard) * kCounterStride; }
 inline __host__ __device__ uint32_t cnt_alive_index(uint32_t parity, uint32_t shard) { return cnt_ext_index(parity, shard) + 1u; }
+// third word of the line: rays traced by the iteration that FILLED this queue; the next iteration folds it into rays[shard]
+inline __host__ __device__ uint32_t cnt_traced_index(uint32_t parity, uint32_t shard) { return cnt_ext_index(parity, shard) + 2u; }
 inline __host__ __device__ uint32_t cnt_bucket_index(uint32_t parity, uint32_t bucket, uint32_t shard)
 {
     return kCntBucket + ((parity * B_COUNT + bucket) * kShards + shard) * kCounterStride;
@@ -79,6 +82,9 @@ struct PathState {           // SoA over slots
     uint32_t shard_cap;      // entries per shard region = slots owned by a shard (multiple of 256)
     uint32_t shard_base, shard_count; // the shards this launch covers: blockIdx.y + shard_base (groups of shards run as
                                       // independent wavefront loops on their own streams, see api.cpp)
+    // queue policy, decided on the device from the shard's own counters (no host lag):
+    float compact_below;     // re-pack a shard's queue when alive < compact_below * length (> 1: always, 0: never)
+    uint32_t finish_below;   // fused kernel: once a shard has no more alive paths than this, a launch runs them to their end
 };
 
 struct FrameParams {

@@ -4,8 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pathtracing_amd as P
 N = P.native
-W, H = 1920, 1080
-spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+W, H = int(os.environ.get('PT_W', '1920')), int(os.environ.get('PT_H', '1080'))
+spp =int(sys.argv[1]) if len(sys.argv) > 1 else 16
 which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["cornell", "glass", "soup", "tess"]
 widths = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2, 4]
 cfg = {"cornell": (N.PT_SCENE_CORNELL, 0, 8), "glass": (N.PT_SCENE_CORNELL_GLASS, 0, 16),
