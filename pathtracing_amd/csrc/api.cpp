@@ -566,7 +566,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             // One kernel per iteration by default: the one-ray-per-lane k_extend shades its own hits (mode 0: Lambert-only
             // scene, lean code; 2: all kinds). The lane-packing kernel and the bucketed pipeline keep k_shade as a second kernel.
             const int shade_mode = s->has_specular ? 2 : 0;
-            const bool fused = !split_kernels && !use_packed;
+            const bool fused = !split_kernels;
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
             HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, use_packed ? packed_chunk : 0u, fused ? shade_mode : -1, compact,
                                      c->bounces));

@@ -462,36 +462,54 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
 #endif
 constexpr uint32_t kRefillIdle = PT_REFILL_IDLE;
 
-template <int L, bool COUNT>
-__global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState ps, uint32_t it, uint32_t chunk)
+//
+// FUSE (as in k_extend): a lane that finishes a ray shades it on the spot and, while the path lives and its budget of
+// `bounces` vertices lasts, starts the path's next ray itself; only then does it hand the slot to the next iteration
+// and pull a new queue entry. Path state stays in registers / LDS across those bounces, and no bounce waits for the wave.
+#ifndef PT_PACKED_WAVES
+#define PT_PACKED_WAVES(FUSE) ((FUSE) == SHADE_NONE ? 7 : 6)
+#endif
+template <int L, bool COUNT, int FUSE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PACKED_WAVES(FUSE), PT_PACKED_WAVES(FUSE))))
+k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint32_t chunk, uint32_t compact, uint32_t bounces)
 {
     constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
     __shared__ int32_t s_stack[kStackLds * 64];
-    const uint32_t parity = it & 1u, ccur = it % 3u, czero = (it + 2u) % 3u;
+    __shared__ uint32_t s_stash[(FUSE != SHADE_NONE ? 5 : 1) * 64];
+    volatile uint32_t *stash = s_stash;
+    const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u, czero = (it + 2u) % 3u;
     const uint32_t shard = blockIdx.y + ps.shard_base;
-    const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)];
+    const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)], n_alive = ps.counters[cnt_alive_index(ccur, shard)];
     const uint32_t lane = threadIdx.x;
+    const bool do_compact = FUSE != SHADE_NONE && want_compact(ps, n, n_alive, compact != 0u);
     if (blockIdx.x == 0 && lane == 0) {
         ps.counters[cnt_ext_index(czero, shard)] = 0u;
         ps.counters[cnt_alive_index(czero, shard)] = 0u;
         fold_traced(ps, shard, it);
-        *traced_counter(ps, (it + 1u) % 3u, shard) = ps.counters[cnt_alive_index(ccur, shard)]; // one ray per alive entry
+        if (FUSE == SHADE_NONE) *traced_counter(ps, cnext, shard) = n_alive; // one ray per alive entry
+        else if (!do_compact) ps.counters[cnt_ext_index(cnext, shard)] = n;  // carried in place: the length stays
+        if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
     }
     uint32_t next = blockIdx.x * chunk;                       // wave-uniform cursor into the shard's queue
-    if (next >= n) return;
+    if (next >= n || n_alive == 0u) return;
     const uint32_t end = min(n, next + chunk);
     const size_t qbase = (size_t)shard * ps.shard_cap;
     const uint32_t *queue = ps.q_ext[parity] + qbase;
+    uint32_t *q_next = ps.q_ext[parity ^ 1u] + qbase;
     const size_t uid = qbase + (size_t)blockIdx.x * 64u + lane; // unique per thread of this launch (chunk >= 64)
     const size_t ovf_stride = (size_t)kShards * ps.shard_cap;
+    const uint32_t budget0 = FUSE == SHADE_NONE ? 1u : (n_alive <= ps.finish_below ? 0xFFFFFFFFu : bounces);
 
     bool has = false;                                          // lane holds a ray
-    uint32_t slot = 0, sp = 0, steps = 0;
+    uint32_t slot = 0, pos = 0, budget = 0, sp = 0, steps = 0;
     int32_t cur = PT_BVH_EMPTY;
-    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
+    PathRegs r;
+    r.o = v3(0.f, 0.f, 0.f); r.d = v3(0.f, 0.f, 1.f); r.T = v3(0.f, 0.f, 0.f); r.key = r.sample = r.depth = 0u;
+    V3 &o = r.o, &d = r.d;
     RaySetup rs = ray_setup(o, d);
     Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
     unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0;
+    uint32_t wave_rays = 0, wave_alive = 0;
 
     auto push = [&](int32_t v) {
         if (sp < kStackLds) s_stack[sp * 64u + lane] = v;
@@ -508,32 +526,68 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
         return sp < kStackLds ? s_stack[sp * 64u + lane] : ps.stack_ovf[(size_t)(sp - kStackLds) * ovf_stride + uid];
     };
 
+    auto start_ray = [&]() { // the lane's ray is in r.o, r.d
+        if (FUSE != SHADE_NONE) { // park what traversal does not need (as in k_extend)
+            stash[0 * 64u + lane] = __float_as_uint(r.T.x); stash[1 * 64u + lane] = __float_as_uint(r.T.y);
+            stash[2 * 64u + lane] = __float_as_uint(r.T.z); stash[3 * 64u + lane] = r.key;
+            stash[4 * 64u + lane] = (r.sample << 8) | r.depth;
+        }
+        h = Hit{ __builtin_inff(), PT_MISS, PT_MISS };
+        for (uint32_t j = 0; j < sc.n_spheres; ++j) {
+            sphere_test(sc.spheres[j], sc.n_tris + j, o, d, h);
+            if (COUNT) c_sph++;
+        }
+        rs = ray_setup(o, d);
+        cur = sc.n_nodes ? 0 : PT_BVH_EMPTY;
+        sp = 0; steps = 0;
+    };
+
     for (;;) {
-        // ---- retire finished rays (wave-uniform point)
+        // ---- finished rays (wave-uniform point): shade, continue the path or retire the slot
         const bool fin = has && cur == PT_BVH_EMPTY;
+        bool retired = false, retire_alive = false;
         if (fin) {
-            ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref));
-            has = false;
+            if (FUSE == SHADE_NONE) {
+                ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref));
+                has = false;
+            } else {
+                r.T = v3(__uint_as_float(stash[0 * 64u + lane]), __uint_as_float(stash[1 * 64u + lane]), __uint_as_float(stash[2 * 64u + lane]));
+                r.key = stash[3 * 64u + lane];
+                const uint32_t sdv = stash[4 * 64u + lane];
+                r.sample = sdv >> 8; r.depth = sdv & 255u;
+                uint32_t defer = 0u;
+                const bool alive = shade_one<FUSE>(sc, ps, fp, slot, r, h.t, h.ref, B_LAMBERT, defer);
+                --budget;
+                if (alive && budget != 0u) start_ray(); // next vertex of the same path, state still in registers
+                else {
+                    if (alive) path_store(ps, slot, r);
+                    retired = true; retire_alive = alive; has = false;
+                }
+            }
+        }
+        if (FUSE != SHADE_NONE) {
+            wave_rays += (uint32_t)__popcll(__ballot(fin && has));
+            wave_alive += (uint32_t)__popcll(__ballot(retire_alive));
+            if (do_compact) wave_push(&ps.counters[cnt_ext_index(cnext, shard)], q_next, retire_alive, slot);
+            else if (retired) q_next[pos] = retire_alive ? slot : kInvalidSlot; // the entry keeps its queue position
         }
         // ---- refill idle lanes from the wave's chunk
         const uint64_t idle = __ballot(!has);
         const uint32_t avail = end - next;
         if (idle && avail) {
             const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            if (!has && prefix < avail) slot = queue[next + prefix];
-            if (!has && prefix < avail && slot != kInvalidSlot) { // a hole leaves the lane idle until the next refill
-                const float4 O = ps.ray_o[slot], D = ps.ray_d[slot];
-                o = xyz(O); d = xyz(D);
-                h = Hit{ __builtin_inff(), PT_MISS, PT_MISS };
-                for (uint32_t j = 0; j < sc.n_spheres; ++j) {
-                    sphere_test(sc.spheres[j], sc.n_tris + j, o, d, h);
-                    if (COUNT) c_sph++;
-                }
-                rs = ray_setup(o, d);
-                cur = sc.n_nodes ? 0 : PT_BVH_EMPTY;
-                sp = 0; steps = 0;
+            const bool pull = !has && prefix < avail;
+            if (pull) { pos = next + prefix; slot = queue[pos]; }
+            if (pull && slot == kInvalidSlot) { // a hole leaves the lane idle until the next refill
+                if (FUSE != SHADE_NONE && !do_compact) q_next[pos] = kInvalidSlot;
+            } else if (pull) {
+                if (FUSE == SHADE_NONE) { o = xyz(ps.ray_o[slot]); d = xyz(ps.ray_d[slot]); }
+                else path_load(ps, slot, r);
+                budget = budget0;
+                start_ray();
                 has = true;
             }
+            if (FUSE != SHADE_NONE) wave_rays += (uint32_t)__popcll(__ballot(pull && has));
             next += min((uint32_t)__popcll(idle), avail);
         }
         if (!__ballot(has)) {
@@ -565,13 +619,22 @@ __global__ void __launch_bounds__(64) k_extend_packed(DeviceScene sc, PathState 
                 }
             }
             const uint32_t busy = (uint32_t)__popcll(__ballot(has && cur != PT_BVH_EMPTY));
-            if (busy == 0u || 64u - busy >= want) break;
+            if (FUSE == SHADE_NONE) { if (busy == 0u || 64u - busy >= want) break; }
+            else { // lanes that can do something at the uniform point: finished rays to shade, empty lanes that can pull
+                const uint32_t waiting = (uint32_t)__popcll(__ballot(has && cur == PT_BVH_EMPTY));
+                const uint32_t empty = (next < end) ? (uint32_t)__popcll(__ballot(!has)) : 0u;
+                if (busy == 0u || waiting + empty >= kRefillIdle) break;
+            }
         }
     }
     if (COUNT) {
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);
+    }
+    if (FUSE != SHADE_NONE && lane == 0u) {
+        if (wave_rays) atomicAdd(traced_counter(ps, cnext, shard), (unsigned long long)wave_rays);
+        if (wave_alive) atomicAdd(&ps.counters[cnt_alive_index(cnext, shard)], wave_alive);
     }
 }
 
@@ -689,7 +752,9 @@ template <int L, bool C>
 static void extend_lc(hipStream_t s, dim3 grid, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t chunk, int fuse,
                       uint32_t cm, uint32_t bounces)
 {
-    if (chunk) hipLaunchKernelGGL((k_extend_packed<L, C>), grid, dim3(64), 0, s, sc, ps, it, chunk);
+    if (chunk && fuse == SHADE_QUEUE) hipLaunchKernelGGL((k_extend_packed<L, C, SHADE_QUEUE>), grid, dim3(64), 0, s, sc, ps, fp, it, chunk, cm, bounces);
+    else if (chunk && fuse == SHADE_INLINE) hipLaunchKernelGGL((k_extend_packed<L, C, SHADE_INLINE>), grid, dim3(64), 0, s, sc, ps, fp, it, chunk, cm, bounces);
+    else if (chunk) hipLaunchKernelGGL((k_extend_packed<L, C, SHADE_NONE>), grid, dim3(64), 0, s, sc, ps, fp, it, chunk, cm, bounces);
     else if (fuse == SHADE_QUEUE) hipLaunchKernelGGL((k_extend<L, C, SHADE_QUEUE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm, bounces);
     else if (fuse == SHADE_INLINE) hipLaunchKernelGGL((k_extend<L, C, SHADE_INLINE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm, bounces);
     else hipLaunchKernelGGL((k_extend<L, C, SHADE_NONE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm, bounces);

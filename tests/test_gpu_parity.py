@@ -311,7 +311,7 @@ def test_shard_groups_on_separate_streams(P, pto, monkeypatch):
     assert all(f[0] == frames[0][0] and np.array_equal(f[1], frames[0][1]) for f in frames)
 
 
-@pytest.mark.parametrize("flags", [0, 4, 64])  # fused extend+shade, lane-packing extend + k_shade, PT_FLAG_SPLIT_KERNELS: all skip holes
+@pytest.mark.parametrize("flags", [0, 4, 64, 68])  # fused one-ray-per-lane / lane-packing kernels, and each followed by k_shade (PT_FLAG_SPLIT_KERNELS)
 def test_queue_compaction_policy_is_invisible(P, pto, monkeypatch, flags):
     """PTRT_COMPACT: queues carried over in place with holes (0 = never re-packed), re-packed every iteration (2), or
     re-packed when alive/length < 0.9 — scheduling only: frame and ray count stay the oracle's. The streams end at
