@@ -43,9 +43,11 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--max-depth", type=int, default=8)
-    ap.add_argument("--streams", type=int, default=0,
-                    help="sample streams per pixel in flight (docs/SPEC.md §5); 0 = 8 x ranks (<= 64), so that every rank keeps "
-                         "as many rays in flight on 1/N of the pixels as one GPU does on the whole frame")
+    ap.add_argument("--streams", type=int, default=8,
+                    help="sample streams per pixel in flight (docs/SPEC.md §5). 8 for every N: the fused kernel keeps a path's state "
+                         "in registers over several vertices and refills a finished path from its own stream, so it wants samples "
+                         "per stream more than it wants slots (measured per-rank share at N=8: 8 streams 4.11 ms, 32 streams 4.85 ms); "
+                         "and with one K the N-rank frame is the single-rank frame bit for bit")
     ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default (68 = BVH4Q)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -65,8 +67,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if args.streams == 0:
-        args.streams = min(64, 8 * world)  # same samples and paths for every N; only the grouping of float additions follows K
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libptrt has no CPU path")
     device = 0 if args.rehearse_gloo else local_rank

@@ -24,6 +24,7 @@ thread_local std::string g_err;
 constexpr uint32_t kLag = 4; // wavefront iterations kept in flight before the host looks at a queue size
 constexpr uint32_t kRingWords = kShards * kCounterStride; // one iteration's readback: (up to) the kShards extend-queue sizes
 constexpr uint32_t kMaxGroups = 4;  // independent wavefront loops (shard groups) per frame, each on its own stream
+constexpr uint32_t kTwoLoopsBelow = 12u << 20; // slots; see pt_context::groups
 constexpr size_t kFinalOffset = (size_t)kMaxGroups * kLag * kRingWords; // where the frame-end copy of all counters lands in h_counts
 
 uint32_t host_pcg(uint32_t x)
@@ -65,14 +66,17 @@ struct pt_context {
     hipEvent_t ev_lag[kMaxGroups][kLag] = {};
     hipStream_t group_stream[kMaxGroups] = {}; // group 0 runs on `stream` when there is one group only
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups] = {};
-    uint32_t groups = 1;                        // PTRT_GROUPS (1, 2, 4) overrides. 2 measured +2.5 % (Cornell 1M) ... +14 % (soup);
-                                                // the default stays 1 so that a launch timed by HIP events, by rocprofv3 and
-                                                // in the benchmark frame is one and the same thing (kernels alone on the GPU)
+    uint32_t groups = 0;                        // PTRT_GROUPS (1, 2, 4) overrides; 0 = by frame size: frames of <= kTwoLoopsBelow slots run
+                                                // two loops, whose launch tails overlap (1M-tri Cornell: a rank's 1/8 of the 1080p frame
+                                                // 4.11 -> 3.81 ms, 1/4 7.14 -> 6.62 ms; four loops are slower, the host cannot feed them).
+                                                // Big frames (the 1-GPU headline: 16.6 M slots) keep one loop: the gain is 3 % there, and a
+                                                // launch timed by HIP events, by rocprofv3 and in the benchmark frame stays one and the same thing
     uint32_t bounces = 4;                       // PTRT_BOUNCES (1..64): path vertices per launch of the fused kernel (state in registers)
     double compact_below = 0.9;                // PTRT_COMPACT overrides: a shard re-packs its queue in an iteration that starts with
                                                 // alive/length below this (>1 = every iteration, 0 = never); else carried in place.
                                                 // Measured (1M-tri Cornell): 1080p/64spp 0.75: 10786, 0.9: 11190, always: 11354 Mrays/s;
                                                 // 4K/1024spp 0.9: 12471, always: 11430 — re-packing mixes wavefronts, long frames feel it
+    double sparse_below = 0.6;                  // PTRT_SPARSE overrides (0 = off): see PathState::sparse_below
     uint32_t finish_below = 4096;             // PTRT_FINISH overrides: a shard with no more alive paths than this runs them to
                                                 // their end in one launch of the fused kernel (0 = never)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -185,6 +189,7 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
     bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * (kFinalOffset + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
     if (const char *e = getenv("PTRT_GROUPS")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4) c->groups = (uint32_t)g; }
     if (const char *e = getenv("PTRT_BOUNCES")) { const int b = atoi(e); if (b >= 1 && b <= 64) c->bounces = (uint32_t)b; }
+    if (const char *e = getenv("PTRT_SPARSE")) { const double v = atof(e); if (v >= 0.0 && v <= 1.0) c->sparse_below = v; }
     if (const char *e = getenv("PTRT_FINISH")) { const long v = atol(e); if (v >= 0 && v <= (1l << 30)) c->finish_below = (uint32_t)v; }
     if (const char *e = getenv("PTRT_COMPACT")) { const double v = atof(e); if (v >= 0.0 && v <= 2.0) c->compact_below = v; }
     for (uint32_t g = 0; ok && g < kMaxGroups; ++g) {
@@ -487,7 +492,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     for (uint32_t b = 0; b < B_COUNT; ++b) ps.q_bucket[b] = c->q_b[b].p;
     ps.counters = c->counters.p; ps.stack_ovf = c->stack_ovf.p; ps.stack_ovf_entries = ovf; ps.n_slots = n_slots; ps.shard_cap = shard_cap;
     ps.shard_base = 0; ps.shard_count = kShards;
-    ps.compact_below = (float)c->compact_below; ps.finish_below = c->finish_below;
+    ps.compact_below = (float)c->compact_below; ps.finish_below = c->finish_below; ps.sparse_below = (float)c->sparse_below;
 
     FrameParams fp{};
     fp.width = p->width; fp.height = p->height; fp.spp = p->spp; fp.max_depth = p->max_depth; fp.rr_start = p->rr_start;
@@ -518,7 +523,9 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     // and the tails of one group's launches are filled by the other's. Measured +13 % (Cornell 1M) ... +22 % (soup) over
     // one loop. Inside a loop a shard's queue can only shrink (slots die, none are born), so the queue sizes read back
     // kLag iterations ago are valid launch bounds: the host never stalls the GPU to size a grid.
-    const uint32_t n_loops = (profile || count) ? 1u : c->groups; // per-kernel timing and visit counting want kernels alone on the GPU
+    // per-kernel timing, visit counting and the extend-kernel probe (events around single iterations) want kernels alone on the GPU
+    const bool will_probe = !(p->flags & (PT_FLAG_EXTEND_PACKED | PT_FLAG_EXTEND_SIMPLE)) && s->ext_choice == 0u;
+    const uint32_t n_loops = (profile || count || will_probe) ? 1u : c->groups ? c->groups : (n_slots <= kTwoLoopsBelow ? 2u : 1u);
     const uint32_t per_group = kShards / n_loops;
     //
     // Queues are carried over IN PLACE from one iteration to the next: a lane writes its own queue position, dead paths

@@ -365,7 +365,10 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     // its stream's next camera ray, so most lanes stay busy); the state goes back to memory once, at the end.
     // Once few paths are left in the shard (the frame's tail) the launch runs them to their end instead: launches that
     // small cost more in launch latency and host round trips than the lanes idling behind a wave's longest path.
-    const uint32_t n_bounces = FUSE == SHADE_NONE ? 1u : (n_alive <= ps.finish_below ? 0xFFFFFFFFu : bounces);
+    // A launch that STARTS sparse (many paths ended during the previous one) runs every wavefront at the cost of its few
+    // live lanes; it advances one vertex only, re-packs, and the dense launch after it does the real work.
+    const bool sparse = do_compact && (float)n_alive < ps.sparse_below * (float)n;
+    const uint32_t n_bounces = FUSE == SHADE_NONE ? 1u : (n_alive <= ps.finish_below ? 0xFFFFFFFFu : sparse ? 1u : bounces);
     for (uint32_t bounce = 0; bounce < n_bounces; ++bounce) {
     const uint64_t alive_mask = __ballot(alive);
     if (alive_mask == 0) break;

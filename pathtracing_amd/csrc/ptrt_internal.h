@@ -84,6 +84,8 @@ struct PathState {           // SoA over slots
                                       // independent wavefront loops on their own streams, see api.cpp)
     // queue policy, decided on the device from the shard's own counters (no host lag):
     float compact_below;     // re-pack a shard's queue when alive < compact_below * length (> 1: always, 0: never)
+    float sparse_below;      // fused one-ray-per-lane kernel: a launch that starts with alive < sparse_below * length advances one
+                             // vertex only (and re-packs), instead of running `bounces` vertices on mostly idle wavefronts
     uint32_t finish_below;   // fused kernel: once a shard has no more alive paths than this, a launch runs them to their end
 };
 
