@@ -76,7 +76,7 @@ struct pt_context {
                                                 // alive/length below this (>1 = every iteration, 0 = never); else carried in place.
                                                 // Measured (1M-tri Cornell): 1080p/64spp 0.75: 10786, 0.9: 11190, always: 11354 Mrays/s;
                                                 // 4K/1024spp 0.9: 12471, always: 11430 — re-packing mixes wavefronts, long frames feel it
-    double sparse_below = 0.6;                  // PTRT_SPARSE overrides (0 = off): see PathState::sparse_below
+    double sparse_below = 0.0;                  // PTRT_SPARSE (0 = off, the default: measured ±0): see PathState::sparse_below
     uint32_t finish_below = 4096;             // PTRT_FINISH overrides: a shard with no more alive paths than this runs them to
                                                 // their end in one launch of the fused kernel (0 = never)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
