@@ -2,20 +2,24 @@
 //
 //   k_reference_sphere : the reference's CSMain (Test.hlsl:1-40; dispatch Renderer.cs:1020), one lane = one pixel
 //   k_generate         : camera ray of the first sample of every (owned pixel, sample stream), fills the extend queues
-//   k_extend<L>        : ray -> closest hit. BVH traversal for node layout L, stack in LDS ([level][lane],
-//                        conflict-free), spheres by scalar loads, one 4-row fetch per step for node or triangle
-//   k_extend_packed<L> : the same, with ballot/mbcnt refill of idle lanes from a per-wave chunk of the queue
-//   k_shade<false>     : walks the extend queue: miss / Lambert shaded in place (emission, BSDF sample, Russian
-//                        roulette, accumulate, in-place regeneration of the stream's next sample), specular hits
-//                        deferred to per-kind bucket queues; survivors are compacted into the next extend queue
-//   k_shade<true>      : the metal / dielectric buckets
+//   k_extend<L,C,FUSE> : ray -> closest hit. BVH traversal for node layout L, stack in LDS ([level][lane],
+//                        conflict-free), spheres by scalar loads, one 4-row fetch per step for node or triangle.
+//                        FUSE (the default pipeline): the lane also shades its hit (shade_one: emission, BSDF sample,
+//                        Russian roulette, accumulate, in-place regeneration of the stream's next sample) and goes on
+//                        for up to `bounces` path vertices with the path state in registers, then queues its slot
+//   k_extend_packed<..>: the same, with ballot/mbcnt refill of idle lanes from a per-wave chunk of the queue
+//   k_shade<MODE>      : the split pipeline's second kernel (PT_FLAG_SPLIT_KERNELS / PT_FLAG_BUCKET_SPECULAR): walks
+//                        the queue k_extend<.., SHADE_NONE> just walked; QUEUE/INLINE shade in queue order, BUCKETS
+//                        shades the metal / dielectric hits that QUEUE deferred to per-kind bucket queues
 //   k_reduce_streams   : fixed-order sum of a pixel's stream partials
 //   k_assemble         : tile-major slots (of 1..R ranks) -> row-major float4 + RGBA8 frame
 //
 // One slot per (owned pixel, stream), at most one live path per slot => accumulator RMW without atomics and a
 // per-stream summation order identical to the oracle's.
 // Queues are split into kShards static shards (ptrt_internal.h): blockIdx.y = shard, and every lane of a block only
-// ever sees slots of its own shard, so a wavefront's push goes to exactly one per-shard counter.
+// ever sees slots of its own shard, so a wavefront's push goes to exactly one per-shard counter. Queues are carried
+// from one iteration to the next in place (entry j stays entry j, dead paths leave holes) and re-packed only when a
+// shard's alive/length ratio says so (want_compact); DESIGN.md §3.
 #include "ptrt_internal.h"
 #include "pt_device.h"
 #include <algorithm>
