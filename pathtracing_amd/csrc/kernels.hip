@@ -16,7 +16,7 @@
 //
 // One slot per (owned pixel, stream), at most one live path per slot => accumulator RMW without atomics and a
 // per-stream summation order identical to the oracle's.
-// Queues are split into kShards static shards (ptrt_internal.h): blockIdx.y = shard, and every lane of a block only
+// Queues are split into kShards static shards (ptrt_internal.h): a workgroup belongs to one shard (block_pos), and every lane of a block only
 // ever sees slots of its own shard, so a wavefront's push goes to exactly one per-shard counter. Queues are carried
 // from one iteration to the next in place (entry j stays entry j, dead paths leave holes) and re-packed only when a
 // shard's alive/length ratio says so (want_compact); DESIGN.md §3.
@@ -46,9 +46,46 @@ PT_DEV void wave_push(uint32_t *counter, uint32_t *queue, bool pred, uint32_t va
     if (pred) queue[base + prefix] = value;
 }
 
+// Slot order. A slot is one (pixel slot, stream) pair; 64 consecutive slots are one 8x8 pixel block of one stream (a
+// wavefront). PT_STREAM_INNER: the K streams of a block are K consecutive 64-slot groups, so that wavefronts that run
+// at the same time work on the same few tiles of the image (their primary rays want the same corner of the scene,
+// which then fits the XCDs' 4 MB L2s). Otherwise stream-major: all blocks of stream 0, then stream 1, ...
+#ifndef PT_STREAM_INNER
+#define PT_STREAM_INNER 1
+#endif
+PT_DEV uint32_t slot_stream(uint32_t slot, const FrameParams &fp)
+{
+    return PT_STREAM_INNER ? (slot >> 6) % fp.streams : slot / fp.slots_per_stream;
+}
+PT_DEV uint32_t slot_pixel_slot(uint32_t slot, const FrameParams &fp)
+{
+    return PT_STREAM_INNER ? ((((slot >> 6) / fp.streams) << 6) | (slot & 63u)) : slot % fp.slots_per_stream;
+}
+PT_DEV size_t slot_of(uint32_t pixel_slot, uint32_t stream, uint32_t streams, uint32_t slots_per_stream)
+{
+    return PT_STREAM_INNER ? (((size_t)(pixel_slot >> 6) * streams + stream) << 6) | (pixel_slot & 63u)
+                           : (size_t)stream * slots_per_stream + pixel_slot;
+}
+
+// Which shard and which block of that shard's queue a workgroup is. PT_SHARD_FASTEST: a 1-D grid with the shard as the
+// fastest index, so that workgroups are dispatched in slot order (shard s holds every 64th 256-slot group) and, with the
+// dispatcher dealing workgroups round-robin to the 8 XCDs, a shard's workgroups always land on the same XCD.
+#ifndef PT_SHARD_FASTEST
+#define PT_SHARD_FASTEST 1
+#endif
+PT_DEV void block_pos(const PathState &ps, uint32_t &shard, uint32_t &bx, uint32_t &nbx)
+{
+    if (PT_SHARD_FASTEST) { shard = blockIdx.x % ps.shard_count + ps.shard_base; bx = blockIdx.x / ps.shard_count; nbx = gridDim.x / ps.shard_count; }
+    else { shard = blockIdx.y + ps.shard_base; bx = blockIdx.x; nbx = gridDim.x; }
+}
+static inline dim3 shard_grid(uint32_t blocks, uint32_t shard_count)
+{
+    return PT_SHARD_FASTEST ? dim3(blocks * shard_count) : dim3(blocks, shard_count);
+}
+
 PT_DEV bool slot_pixel(uint32_t slot_all, const FrameParams &fp, uint32_t &x, uint32_t &y)
 {
-    const uint32_t slot = slot_all % fp.slots_per_stream; // the K streams of a pixel share its pixel slot
+    const uint32_t slot = slot_pixel_slot(slot_all, fp); // the K streams of a pixel share its pixel slot
     const uint32_t tl = slot >> (2 * kTileShift), inner = slot & (kTilePixels - 1);
     const uint32_t tile = fp.rank + fp.nranks * tl;
     if (tile >= fp.n_tiles) return false;
@@ -85,13 +122,14 @@ __global__ void __launch_bounds__(kBlock) k_reference_sphere(uint32_t w, uint32_
 // grid (shard_cap/256, kShards): entry j of shard s is slot ((j>>8)*kShards + s)*256 + (j&255)
 __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState ps, FrameParams fp)
 {
-    const uint32_t shard = blockIdx.y + ps.shard_base;
-    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t shard, bx, nbx;
+    block_pos(ps, shard, bx, nbx);
+    const uint32_t j = bx * kBlock + threadIdx.x;
     const uint32_t slot = (((j >> 8) * kShards + shard) << 8) | (j & 255u);
     uint32_t x = 0, y = 0;
     const bool in_range = j < ps.shard_cap && slot < ps.n_slots;
     // stream k takes the samples s with (sample_offset + s) % K == k, in increasing s (docs/SPEC.md §5)
-    const uint32_t stream = slot / fp.slots_per_stream;
+    const uint32_t stream = slot_stream(slot, fp);
     const uint32_t first = (stream + fp.streams - fp.sample_offset % fp.streams) % fp.streams;
     const bool valid = in_range && first < fp.spp && slot_pixel(slot, fp, x, y);
     if (in_range && !fp.accumulate) ps.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -109,7 +147,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState p
     const uint32_t n_alive = (uint32_t)__syncthreads_count(valid);
     if (threadIdx.x == 0) {
         if (n_alive) atomicAdd(&ps.counters[cnt_alive_index(0, shard)], n_alive);
-        if (blockIdx.x == 0) ps.counters[cnt_ext_index(0, shard)] = ps.shard_cap;
+        if (bx == 0) ps.counters[cnt_ext_index(0, shard)] = ps.shard_cap;
     }
 }
 
@@ -337,10 +375,11 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     __shared__ int32_t s_stack[kStackLds * kExtBlock];
     __shared__ uint32_t s_stash[(FUSE != SHADE_NONE ? 5 : 1) * kExtBlock];
     volatile uint32_t *stash = s_stash; // volatile: the values must really leave the registers
-    const uint32_t shard = blockIdx.y + ps.shard_base;
+    uint32_t shard, bx, nbx;
+    block_pos(ps, shard, bx, nbx);
     const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)], n_alive = ps.counters[cnt_alive_index(ccur, shard)];
     const uint32_t tid = threadIdx.x;
-    const uint32_t gid = blockIdx.x * kExtBlock + tid;          // index inside the shard's queue
+    const uint32_t gid = bx * kExtBlock + tid;                  // index inside the shard's queue
     const bool do_compact = FUSE != SHADE_NONE && want_compact(ps, n, n_alive, compact != 0u);
     if (gid == 0) {
         ps.counters[cnt_ext_index(czero, shard)] = 0u;         // the queue after next
@@ -350,7 +389,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
                                                                              // counts what it traces, per wavefront
         if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
     }
-    if (blockIdx.x * kExtBlock >= n || n_alive == 0u) return;
+    if (bx * kExtBlock >= n || n_alive == 0u) return;
     const size_t qbase = (size_t)shard * ps.shard_cap;
     const uint32_t slot = gid < n ? ps.q_ext[parity][qbase + gid] : kInvalidSlot;
     const bool active = slot != kInvalidSlot;                  // holes: paths that ended since the queue was last compacted
@@ -485,11 +524,12 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
     __shared__ uint32_t s_stash[(FUSE != SHADE_NONE ? 5 : 1) * 64];
     volatile uint32_t *stash = s_stash;
     const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u, czero = (it + 2u) % 3u;
-    const uint32_t shard = blockIdx.y + ps.shard_base;
+    uint32_t shard, bx, nbx;
+    block_pos(ps, shard, bx, nbx);
     const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)], n_alive = ps.counters[cnt_alive_index(ccur, shard)];
     const uint32_t lane = threadIdx.x;
     const bool do_compact = FUSE != SHADE_NONE && want_compact(ps, n, n_alive, compact != 0u);
-    if (blockIdx.x == 0 && lane == 0) {
+    if (bx == 0 && lane == 0) {
         ps.counters[cnt_ext_index(czero, shard)] = 0u;
         ps.counters[cnt_alive_index(czero, shard)] = 0u;
         fold_traced(ps, shard, it);
@@ -497,13 +537,13 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
         else if (!do_compact) ps.counters[cnt_ext_index(cnext, shard)] = n;  // carried in place: the length stays
         if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
     }
-    uint32_t next = blockIdx.x * chunk;                       // wave-uniform cursor into the shard's queue
+    uint32_t next = bx * chunk;                               // wave-uniform cursor into the shard's queue
     if (next >= n || n_alive == 0u) return;
     const uint32_t end = min(n, next + chunk);
     const size_t qbase = (size_t)shard * ps.shard_cap;
     const uint32_t *queue = ps.q_ext[parity] + qbase;
     uint32_t *q_next = ps.q_ext[parity ^ 1u] + qbase;
-    const size_t uid = qbase + (size_t)blockIdx.x * 64u + lane; // unique per thread of this launch (chunk >= 64)
+    const size_t uid = qbase + (size_t)bx * 64u + lane;        // unique per thread of this launch (chunk >= 64)
     const size_t ovf_stride = (size_t)kShards * ps.shard_cap;
     const uint32_t budget0 = FUSE == SHADE_NONE ? 1u : (n_alive <= ps.finish_below ? 0xFFFFFFFFu : bounces);
 
@@ -661,21 +701,22 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
 {
     constexpr bool SPEC = MODE == SHADE_BUCKETS;
     const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u;
-    const uint32_t shard = blockIdx.y + ps.shard_base;
+    uint32_t shard, bx, nbx;
+    block_pos(ps, shard, bx, nbx);
     const size_t qbase = (size_t)shard * ps.shard_cap;
     uint32_t total, c0 = 0u;
     if (SPEC) {
         c0 = ps.counters[cnt_bucket_index(parity, B_METAL, shard)];
         total = c0 + ps.counters[cnt_bucket_index(parity, B_DIELECTRIC, shard)];
-        if (blockIdx.x == 0 && threadIdx.x < 2u) // the other parity's buckets were consumed by the previous k_shade<true>
+        if (bx == 0 && threadIdx.x < 2u) // the other parity's buckets were consumed by the previous k_shade<true>
             ps.counters[cnt_bucket_index(parity ^ 1u, B_METAL + threadIdx.x, shard)] = 0u;
     } else total = ps.counters[cnt_ext_index(ccur, shard)];
     const uint32_t n_alive = ps.counters[cnt_alive_index(ccur, shard)];
     const bool do_compact = SPEC || want_compact(ps, total, n_alive, compact != 0u);
-    if (!SPEC && do_compact && n_alive && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ps.counters[kCntCompactions], 1u);
+    if (!SPEC && do_compact && n_alive && bx == 0 && threadIdx.x == 0) atomicAdd(&ps.counters[kCntCompactions], 1u);
     // SPEC: a small fixed grid strides over the (usually short, unknown-length) specular buckets, so an empty bucket
     // costs a few hundred trivial blocks instead of one per 256 queue slots. !SPEC: exactly one pass, grid sized by the host.
-    for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
+    for (uint32_t base = bx * kBlock; base < total; base += nbx * kBlock) {
     const uint32_t gid = base + threadIdx.x;
     uint32_t b = B_LAMBERT, slot = kInvalidSlot;
     if (SPEC) {
@@ -708,11 +749,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
 __global__ void __launch_bounds__(kBlock) k_reduce_streams(const float4 *__restrict__ acc, float4 *__restrict__ tiles,
                                                            uint32_t slots_per_stream, uint32_t streams)
 {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x; // pixel slot
     if (slot >= slots_per_stream) return;
-    float4 t = acc[slot];
+    float4 t = acc[slot_of(slot, 0u, streams, slots_per_stream)];
     for (uint32_t k = 1; k < streams; ++k) {
-        const float4 a = acc[(size_t)k * slots_per_stream + slot];
+        const float4 a = acc[slot_of(slot, k, streams, slots_per_stream)];
         t.x = t.x + a.x; t.y = t.y + a.y; t.z = t.z + a.z; t.w = t.w + a.w;
     }
     tiles[slot] = t;
@@ -751,7 +792,7 @@ hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4
 
 hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp)
 {
-    hipLaunchKernelGGL(k_generate, dim3(blocks_for(ps.shard_cap), kShards), dim3(kBlock), 0, s, sc, ps, fp);
+    hipLaunchKernelGGL(k_generate, shard_grid(blocks_for(ps.shard_cap), ps.shard_count), dim3(kBlock), 0, s, sc, ps, fp);
     return hipGetLastError();
 }
 
@@ -775,7 +816,7 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
     // Measured on MI355X: packing raises lane utilisation but is slower at every chunk size, because the
     // kernel is bound by outstanding divergent node fetches and fewer waves means fewer of them; it stays selectable.
     const uint32_t chunk = packed_chunk >= 64u ? packed_chunk : 0u, per_block = chunk ? chunk : kExtBlock;
-    const dim3 grid(shard_bound ? (shard_bound + per_block - 1) / per_block : 1u, ps.shard_count);
+    const dim3 grid = shard_grid(shard_bound ? (shard_bound + per_block - 1) / per_block : 1u, ps.shard_count);
     const uint32_t cm = compact ? 1u : 0u;
     switch (sc.bvh_width) {
     case PT_BVH_WIDTH_2:  count ? extend_lc<PT_BVH_WIDTH_2, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_2, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
@@ -789,8 +830,8 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
 hipError_t launch_shade(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t shard_bound, int mode, bool compact)
 {
     const uint32_t parity = it; // k_shade derives queue parity and counter rotation from the iteration index
-    const dim3 grid(blocks_for(shard_bound), ps.shard_count), block(kBlock);
-    const dim3 sgrid(std::min(blocks_for(shard_bound), 16u), ps.shard_count); // grid-stride over the specular buckets
+    const dim3 grid = shard_grid(blocks_for(shard_bound), ps.shard_count), block(kBlock);
+    const dim3 sgrid = shard_grid(std::min(blocks_for(shard_bound), 16u), ps.shard_count); // grid-stride over the specular buckets
     const uint32_t cm = compact ? 1u : 0u;
     if (mode == SHADE_BUCKETS) hipLaunchKernelGGL(k_shade<SHADE_BUCKETS>, sgrid, block, 0, s, sc, ps, fp, parity, 1u);
     else if (mode == SHADE_INLINE) hipLaunchKernelGGL(k_shade<SHADE_INLINE>, grid, block, 0, s, sc, ps, fp, parity, cm);
