@@ -148,7 +148,8 @@ def main():
 
     out = None
     if rank == 0:
-        layout = {2: "BVH2 (64-B nodes)", 4: "BVH4 (128-B nodes)", 68: "BVH4Q (64-B quantised nodes)"}.get(info.width, str(info.width))
+        layout = {2: "BVH2 (64-B nodes)", 4: "BVH4 (128-B nodes)", 68: "BVH4Q (64-B quantised nodes)",
+                  72: "BVH8Q (128-B lines, 96 B used)"}.get(info.width, str(info.width))
         workload = (f"{args.scene}: {info.n_tris} triangles + {len(sd.sph_mat)} spheres, {layout}, {info.n_nodes} nodes, {W}x{H}, "
                     f"{args.spp} spp, max depth {args.max_depth}, RR from depth 3, implicit light hits only, {args.streams} sample "
                     f"streams per pixel; the north_star headline scene (BASELINE configs[4]'s 1M-triangle Cornell at configs[1]'s "
@@ -170,7 +171,7 @@ def main():
         n_nodes_ray = sc.node_visits / sc.rays
         n_tris_ray = sc.tri_tests / sc.rays
         n_sph_ray = sc.sphere_tests / sc.rays
-        node_bytes = 64.0 if info.width in (2, 68) else 128.0
+        node_bytes = {2: 64.0, 4: 128.0, 68: 64.0, 72: 96.0}[info.width]
         fused = sp.shade_ms < 0.05 * sp.extend_ms  # the default pipeline: k_extend shades its own hits, several bounces per launch
         # algorithmic bytes the dominant kernel must move per ray:
         #   traversal : node / triangle / sphere bytes of the visits it makes

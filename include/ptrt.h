@@ -69,10 +69,12 @@ enum {
 };
 /* pt_scene_commit options */
 enum {
-    PT_BVH_WIDTH_DEFAULT = 0, /* = PT_BVH_WIDTH_4Q */
+    PT_BVH_WIDTH_DEFAULT = 0, /* PT_BVH_WIDTH_4Q; PT_BVH_WIDTH_8Q for scenes of at most 256 triangles (pt_bvh_info.width tells) */
     PT_BVH_WIDTH_2 = 2,       /* binary, 64-B nodes, f32 child boxes */
     PT_BVH_WIDTH_4 = 4,       /* 4-wide, 128-B nodes, f32 child boxes */
     PT_BVH_WIDTH_4Q = 68,     /* 4-wide, 64-B nodes, child boxes quantised to 8 bits on a per-node power-of-two grid */
+    PT_BVH_WIDTH_8Q = 72,     /* 8-wide, one 128-B cache line per node (96 B used), the same quantisation: a node visit costs the
+                                 memory system one line either way, and there are fewer visits */
     PT_BVH_BUILD_LBVH = 0x100 /* OR-ed onto a layout: build the hierarchy on the GPU (Morton sort + Karras + refit) instead of the
                                  host's binned-SAH builder. Faster to build, slower to trace; the picture is identical either way. */
 };

@@ -187,8 +187,23 @@ static inline void test_sphere(const pto_scene *s, uint32_t j, v3 o, v3 d, hit_t
  * layout 2 / 4: N slots of 32 B. layout 68 (BVH4Q): one 64-byte node
  *   +0 origin f32[3] | +12 exponent u8[3],0 | +16 ref i32[4] | +32 qlo_x,qlo_y,qlo_z (u8[4] each) | +44 qhi_x,qhi_y,qhi_z
  * with box = fma((float)q, 2^(e-127), origin) per axis. */
-static uint32_t node_children(uint32_t layout, const void *nodes, uint32_t i, slot_t out[4])
+static uint32_t node_children(uint32_t layout, const void *nodes, uint32_t i, slot_t out[8])
 {
+    if (layout == PTO_BVH_LAYOUT_8Q) { /* 128-byte node: +16 ref i32[8] | +48 qlo_x,qlo_y,qlo_z (u8[8] each) | +72 qhi_x,qhi_y,qhi_z */
+        const uint8_t *nd = (const uint8_t *)nodes + (size_t)i * 128;
+        float org[3], sc[3];
+        memcpy(org, nd, 12);
+        for (int k = 0; k < 3; ++k) sc[k] = bits2f((uint32_t)nd[12 + k] << 23);
+        for (int c = 0; c < 8; ++c) {
+            memcpy(&out[c].ref, nd + 16 + 4 * c, 4);
+            out[c].aux = 0;
+            for (int k = 0; k < 3; ++k) {
+                out[c].lo[k] = fma_((float)nd[48 + 8 * k + c], sc[k], org[k]);
+                out[c].hi[k] = fma_((float)nd[72 + 8 * k + c], sc[k], org[k]);
+            }
+        }
+        return 8;
+    }
     if (layout == PTO_BVH_LAYOUT_4Q) {
         const uint8_t *nd = (const uint8_t *)nodes + (size_t)i * 64;
         float org[3], sc[3];
@@ -230,8 +245,9 @@ static void closest_hit(const pto_scene *s, v3 o, v3 d, hit_t *h, pto_stats *st)
     while (sp > 0) {
         int32_t ref = stack[--sp];
         if (ref >= 0) {
-            slot_t nd[4];
+            slot_t nd[8];
             const uint32_t N = node_children(s->bvh_width, s->nodes, (uint32_t)ref, nd);
+            const uint32_t slot_mask = N > 4 ? 7u : 3u; /* low key bits that carry the slot index (SPEC §4.2) */
             st->node_visits++;
             uint32_t keys[8]; int32_t refs[8]; int nh = 0;
             for (uint32_t c = 0; c < N; ++c) {
@@ -241,7 +257,7 @@ static void closest_hit(const pto_scene *s, v3 o, v3 d, hit_t *h, pto_stats *st)
                 float taz = fma_(nd[c].lo[2], inv[2], noi[2]), tbz = fma_(nd[c].hi[2], inv[2], noi[2]);
                 float tn = max_(max_(min_(tax, tbx), min_(tay, tby)), max_(min_(taz, tbz), 0.0f));
                 float tf = min_(min_(max_(tax, tbx), max_(tay, tby)), min_(max_(taz, tbz), h->t)) * 1.0000004f;
-                if (tn <= tf) { keys[nh] = (f2bits(tn) & ~3u) | c; refs[nh] = nd[c].ref; nh++; }
+                if (tn <= tf) { keys[nh] = (f2bits(tn) & ~slot_mask) | c; refs[nh] = nd[c].ref; nh++; }
             }
             /* push in descending key order */
             for (int i = 1; i < nh; ++i) {
@@ -454,7 +470,7 @@ int pto_render(const pto_scene *s, const pto_params *p, int threads, float *rgba
     for (uint32_t i = 0; i < s->n_tris; ++i) if (s->tri_mat && s->tri_mat[i] >= s->n_mats) return -3;
     for (uint32_t i = 0; i < s->n_spheres; ++i) if (s->sph_mat && s->sph_mat[i] >= s->n_mats) return -3;
     if ((s->n_tris || s->n_spheres) && s->n_mats == 0) return -3;
-    if (s->nodes && s->bvh_width != 2 && s->bvh_width != 4 && s->bvh_width != PTO_BVH_LAYOUT_4Q) return -4;
+    if (s->nodes && s->bvh_width != 2 && s->bvh_width != 4 && s->bvh_width != PTO_BVH_LAYOUT_4Q && s->bvh_width != PTO_BVH_LAYOUT_8Q) return -4;
     pto_stats tot; memset(&tot, 0, sizeof tot);
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
@@ -590,10 +606,10 @@ void pto_free(void *p) { free(p); }
 int pto_bvh_validate(uint32_t width, uint32_t n_nodes, const void *nodes_v, const void *tris_v,
                      uint32_t n_tris, const float *tri_verts, const uint32_t *tri_mat, uint32_t *max_depth_out)
 {
-    if (width != 2 && width != 4 && width != PTO_BVH_LAYOUT_4Q) return -1;
+    if (width != 2 && width != 4 && width != PTO_BVH_LAYOUT_4Q && width != PTO_BVH_LAYOUT_8Q) return -1;
     if (n_tris == 0) return n_nodes == 0 ? 0 : -2;
     if (n_nodes == 0 || !nodes_v || !tris_v) return -2;
-    const uint32_t W = (width == 2) ? 2u : 4u;
+    const uint32_t W = (width == 2) ? 2u : (width == PTO_BVH_LAYOUT_8Q) ? 8u : 4u;
     const tri48_t *tris = (const tri48_t *)tris_v;
     uint8_t *seen = (uint8_t *)calloc(n_tris, 1), *nseen = (uint8_t *)calloc(n_nodes, 1);
     typedef struct { int32_t ref; box_t box; uint32_t depth; } ent;
@@ -609,7 +625,7 @@ int pto_bvh_validate(uint32_t width, uint32_t n_nodes, const void *nodes_v, cons
         if (e.ref >= 0) {
             if ((uint32_t)e.ref >= n_nodes) { rc = -4; break; }
             if (nseen[e.ref]++) { rc = -5; break; } /* node reachable twice */
-            slot_t nd[4];
+            slot_t nd[8];
             node_children(width, nodes_v, (uint32_t)e.ref, nd);
             int any = 0;
             for (uint32_t c = 0; c < W; ++c) {

@@ -97,9 +97,10 @@ struct pt_scene {
     bool have_cam = false, committed = false;
     BvhBlob bvh;
     uint32_t layout = 0;                 // PT_BVH_WIDTH_* the scene was committed with
-    std::vector<uint8_t> packed_nodes;   // layout PT_BVH_WIDTH_4Q: the 64-byte nodes that are uploaded / read back
-    const void *node_data() const { return layout == PT_BVH_WIDTH_4Q ? (const void *)packed_nodes.data() : (const void *)bvh.slots.data(); }
-    uint64_t node_bytes() const { return layout == PT_BVH_WIDTH_4Q ? packed_nodes.size() : bvh.slots.size() * sizeof(BvhSlot); }
+    std::vector<uint8_t> packed_nodes;   // layouts PT_BVH_WIDTH_4Q / _8Q: the 64- / 128-byte nodes that are uploaded / read back
+    bool quantised() const { return layout == PT_BVH_WIDTH_4Q || layout == PT_BVH_WIDTH_8Q; }
+    const void *node_data() const { return quantised() ? (const void *)packed_nodes.data() : (const void *)bvh.slots.data(); }
+    uint64_t node_bytes() const { return quantised() ? packed_nodes.size() : bvh.slots.size() * sizeof(BvhSlot); }
     DevBuf<float4> d_nodes, d_tris, d_spheres, d_mats;
     bool has_specular = false;
     uint32_t ext_choice = 0;             // extend kernel picked by the probe of an earlier frame (0 = none yet, 1 = simple, 2 = packed)
@@ -319,16 +320,19 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     const bool lbvh = (bvh_width & PT_BVH_BUILD_LBVH) != 0; // hierarchy built on the GPU instead of the host SAH builder
     bvh_width &= ~(uint32_t)PT_BVH_BUILD_LBVH;
     if (lbvh && !c) return fail(c, PT_ERR_UNSUPPORTED, "PT_BVH_BUILD_LBVH needs a device context (detached scenes use the host builder)");
-    if (bvh_width == PT_BVH_WIDTH_DEFAULT) bvh_width = PT_BVH_WIDTH_4Q;
-    if (bvh_width != PT_BVH_WIDTH_2 && bvh_width != PT_BVH_WIDTH_4 && bvh_width != PT_BVH_WIDTH_4Q)
-        return fail(c, PT_ERR_INVALID_ARGUMENT, "bvh_width must be one of PT_BVH_WIDTH_* (0, 2, 4, 68)");
+    // default layout: BVH4Q; scenes of a few hundred triangles get BVH8Q — their whole tree is a handful of L1-resident lines and
+    // what counts is the number of dependent steps (Cornell: 1 node instead of 2 levels, 23.6 -> 24.8 Grays/s; Cornell+glass+metal
+    // 17.6 -> 20.0), while on big trees the 8-wide visit costs more ALU than the saved visits are worth (1M triangles: 11.1 vs 8.5)
+    if (bvh_width == PT_BVH_WIDTH_DEFAULT) bvh_width = s->tri_mat.size() <= 256 ? PT_BVH_WIDTH_8Q : PT_BVH_WIDTH_4Q;
+    if (bvh_width != PT_BVH_WIDTH_2 && bvh_width != PT_BVH_WIDTH_4 && bvh_width != PT_BVH_WIDTH_4Q && bvh_width != PT_BVH_WIDTH_8Q)
+        return fail(c, PT_ERR_INVALID_ARGUMENT, "bvh_width must be one of PT_BVH_WIDTH_* (0, 2, 4, 68, 72)");
     if (!s->have_cam) return fail(c, PT_ERR_INVALID_ARGUMENT, "no camera set");
     const uint32_t nt = (uint32_t)s->tri_mat.size(), ns = (uint32_t)s->sph_mat.size(), nm = (uint32_t)s->mats.size();
     if ((nt || ns) && nm == 0) return fail(c, PT_ERR_INVALID_ARGUMENT, "primitives but no materials");
     for (uint32_t i = 0; i < nt; ++i) if (s->tri_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "triangle %u: material id %u >= %u", i, s->tri_mat[i], nm);
     for (uint32_t i = 0; i < ns; ++i) if (s->sph_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "sphere %u: material id %u >= %u", i, s->sph_mat[i], nm);
 
-    const uint32_t fan = bvh_width == PT_BVH_WIDTH_2 ? 2u : 4u;
+    const uint32_t fan = bvh_width == PT_BVH_WIDTH_2 ? 2u : bvh_width == PT_BVH_WIDTH_8Q ? 8u : 4u;
     if (lbvh && nt >= 2) {
         HIP_TRY(c, hipSetDevice(c->device));
         BinaryBvh bt;
@@ -339,6 +343,7 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     s->layout = bvh_width;
     s->packed_nodes.clear();
     if (bvh_width == PT_BVH_WIDTH_4Q) quantize_bvh4(s->bvh, s->packed_nodes);
+    if (bvh_width == PT_BVH_WIDTH_8Q) quantize_bvh8(s->bvh, s->packed_nodes);
     if (!c) { s->committed = true; return PT_OK; } // detached scene: host-side blob only
 
     HIP_TRY(c, hipSetDevice(c->device));

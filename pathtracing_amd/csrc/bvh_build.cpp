@@ -117,7 +117,7 @@ struct Builder {
 void emit_blob(const std::vector<Tmp> &tn, int32_t root, const std::vector<uint32_t> &idx, const float *verts9, const uint32_t *mats,
                uint32_t n_tris, uint32_t width, BvhBlob &out)
 {
-    struct Pending { int32_t kids[4]; int nk; };
+    struct Pending { int32_t kids[8]; int nk; }; // width <= 8
     std::vector<Pending> pend;
     pend.reserve(tn.size());
     auto expand = [&](int32_t t) { // children of the output node made from tmp node t
@@ -142,7 +142,7 @@ void emit_blob(const std::vector<Tmp> &tn, int32_t root, const std::vector<uint3
     double sah = 0.0;
     for (size_t i = 0; i < pend.size(); ++i) { // pend grows while we iterate: index i = output node i
         const Pending p = pend[i];
-        BvhSlot s[4];
+        BvhSlot s[8];
         for (uint32_t c = 0; c < width; ++c) { std::memset(&s[c], 0, sizeof(BvhSlot)); s[c].ref = kEmpty; }
         for (int c = 0; c < p.nk; ++c) {
             const Tmp &k = tn[p.kids[c]];
@@ -265,17 +265,20 @@ namespace {
 inline float scale_of(uint8_t e) { uint32_t b = (uint32_t)e << 23; float f; std::memcpy(&f, &b, 4); return f; }
 } // namespace
 
-void quantize_bvh4(const BvhBlob &in, std::vector<uint8_t> &out)
+// N = 4: 64-byte nodes (layout 68); N = 8: 128-byte nodes (layout 72), same scheme with 8-byte coordinate groups
+template <int N>
+static void quantize_nodes(const BvhBlob &in, std::vector<uint8_t> &out)
 {
-    out.assign((size_t)in.n_nodes * 64, 0);
+    constexpr size_t kStride = N == 4 ? 64 : 128, kQ = 16 + 4 * N; // quantised coordinates start after origin|exps and the refs
+    out.assign((size_t)in.n_nodes * kStride, 0);
     for (uint32_t i = 0; i < in.n_nodes; ++i) {
-        const BvhSlot *s = &in.slots[(size_t)i * 4];
-        uint8_t *nd = &out[(size_t)i * 64];
+        const BvhSlot *s = &in.slots[(size_t)i * N];
+        uint8_t *nd = &out[(size_t)i * kStride];
         float org[3]; uint8_t ex[3];
-        uint8_t qlo[3][4] = {}, qhi[3][4] = {};
+        uint8_t qlo[3][N] = {}, qhi[3][N] = {};
         for (int k = 0; k < 3; ++k) {
             float lo = kInf, hi = -kInf;
-            for (int c = 0; c < 4; ++c) if (s[c].ref != kEmpty) { lo = std::min(lo, s[c].lo[k]); hi = std::max(hi, s[c].hi[k]); }
+            for (int c = 0; c < N; ++c) if (s[c].ref != kEmpty) { lo = std::min(lo, s[c].lo[k]); hi = std::max(hi, s[c].hi[k]); }
             if (!(lo <= hi)) { lo = hi = 0.f; } // node without children (cannot happen for a built tree)
             org[k] = lo;
             int e = 1;
@@ -288,7 +291,7 @@ void quantize_bvh4(const BvhBlob &in, std::vector<uint8_t> &out)
             for (;;) { // quantise; widen the grid if a coordinate does not fit in 8 bits
                 const float sc = scale_of((uint8_t)e);
                 bool ok = true;
-                for (int c = 0; c < 4 && ok; ++c) {
+                for (int c = 0; c < N && ok; ++c) {
                     if (s[c].ref == kEmpty) continue;
                     int ql = (int)std::floor((s[c].lo[k] - lo) / sc), qh = (int)std::ceil((s[c].hi[k] - lo) / sc);
                     ql = std::min(std::max(ql, 0), 255); qh = std::min(std::max(qh, 0), 255);
@@ -304,9 +307,12 @@ void quantize_bvh4(const BvhBlob &in, std::vector<uint8_t> &out)
         }
         std::memcpy(nd + 0, org, 12);
         nd[12] = ex[0]; nd[13] = ex[1]; nd[14] = ex[2]; nd[15] = 0;
-        for (int c = 0; c < 4; ++c) std::memcpy(nd + 16 + 4 * c, &s[c].ref, 4);
-        for (int k = 0; k < 3; ++k) { std::memcpy(nd + 32 + 4 * k, qlo[k], 4); std::memcpy(nd + 44 + 4 * k, qhi[k], 4); }
+        for (int c = 0; c < N; ++c) std::memcpy(nd + 16 + 4 * c, &s[c].ref, 4);
+        for (int k = 0; k < 3; ++k) { std::memcpy(nd + kQ + N * k, qlo[k], N); std::memcpy(nd + kQ + N * (3 + k), qhi[k], N); }
     }
 }
+
+void quantize_bvh4(const BvhBlob &in, std::vector<uint8_t> &out) { quantize_nodes<4>(in, out); }
+void quantize_bvh8(const BvhBlob &in, std::vector<uint8_t> &out) { quantize_nodes<8>(in, out); }
 
 } // namespace ptrt

@@ -10,7 +10,7 @@ struct BvhSlot { float lo[3]; int32_t ref; float hi[3]; uint32_t aux; };        
 struct BvhTri { float v0[3]; uint32_t id; float e1[3]; uint32_t mat; float e2[3]; uint32_t pad; };    // 48 B
 
 struct BvhBlob {
-    uint32_t width = 0;               // 2 or 4
+    uint32_t width = 0;               // 2, 4 or 8
     std::vector<BvhSlot> slots;       // n_nodes * width
     std::vector<BvhTri> tris;         // leaf order
     uint32_t n_nodes = 0, max_depth = 0, stack_need = 0;
@@ -18,7 +18,7 @@ struct BvhBlob {
     double build_ms = 0.0;
 };
 
-// verts9: 9 floats per triangle; mats may be null (all 0). width: 2 or 4.
+// verts9: 9 floats per triangle; mats may be null (all 0). width: 2, 4 or 8.
 void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out);
 
 // Binary LBVH as the device builder (lbvh.hip) returns it: n leaves of one triangle each in Morton order, n-1 internal nodes, node 0 = root.
@@ -35,5 +35,8 @@ void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint3
 // BVH4Q (layout id 68): repack a width-4 blob into 64-byte nodes with 8-bit child boxes:
 //   +0 origin f32[3] | +12 exponent u8[3],0 | +16 ref i32[4] | +32 qlo_x,qlo_y,qlo_z u8[4] each | +44 qhi_x,qhi_y,qhi_z | +56 pad
 void quantize_bvh4(const BvhBlob &in, std::vector<uint8_t> &out);
+// BVH8Q (layout id 72): a width-8 blob in 128-byte nodes (96 used), the same scheme with 8 children:
+//   +0 origin f32[3] | +12 exponent u8[3],0 | +16 ref i32[8] | +48 qlo_x,qlo_y,qlo_z u8[8] each | +72 qhi_x,qhi_y,qhi_z | +96 pad
+void quantize_bvh8(const BvhBlob &in, std::vector<uint8_t> &out);
 
 } // namespace ptrt

@@ -159,21 +159,50 @@ __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState p
 //             -> 4 loads per lane: half the bytes and half the (fully divergent) memory instructions per visit.
 // The first four 16-byte rows of the node arrive in r0..r3: the caller loads them (from the node OR, for a lane that
 // sits on a leaf, from its triangle) before it branches, so a wave-iteration has one memory round trip, not two.
+// L = 8Q    : one 128-byte line per node {origin|exps, 8 refs, qlo x|y, qlo z|qhi x, qhi y|z, pad} -> 6 loads per lane.
+//             Beyond the caches a node visit costs the memory system one 128-byte line whether 64 or 96 bytes of it are
+//             used (tools/ubench/gather_rows.hip), and an 8-wide tree needs fewer visits. Keys keep 3 bits for the slot.
 template <int L>
-PT_DEV constexpr int node_rows() { return L == PT_BVH_WIDTH_4 ? 8 : 4; }
+PT_DEV constexpr int node_rows() { return (L == PT_BVH_WIDTH_4 || L == PT_BVH_WIDTH_8Q) ? 8 : 4; }
+template <int L>
+PT_DEV constexpr int fanout() { return L == PT_BVH_WIDTH_2 ? 2 : L == PT_BVH_WIDTH_8Q ? 8 : 4; }
 
 template <int L>
 PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, float4 r2, float4 r3, const RaySetup &rs, float t_best,
-                       uint32_t (&key)[4], int32_t (&ref)[4])
+                       uint32_t (&key)[fanout<L>()], int32_t (&ref)[fanout<L>()])
 {
-    constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
-    if (L == PT_BVH_WIDTH_4Q) {
+    constexpr int N = fanout<L>();
+    if constexpr (L == PT_BVH_WIDTH_8Q) {
+        const float4 r4 = nd[4], r5 = nd[5];
+        const uint32_t eb = __float_as_uint(r0.w);
+        const float sx = __uint_as_float((eb & 0xffu) << 23), sy = __uint_as_float(((eb >> 8) & 0xffu) << 23),
+                    sz = __uint_as_float(((eb >> 16) & 0xffu) << 23);
+        // 8 bytes per coordinate: children 0-3 in the first dword, 4-7 in the second
+        const uint32_t q[6][2] = { { __float_as_uint(r3.x), __float_as_uint(r3.y) }, { __float_as_uint(r3.z), __float_as_uint(r3.w) },
+                                   { __float_as_uint(r4.x), __float_as_uint(r4.y) }, { __float_as_uint(r4.z), __float_as_uint(r4.w) },
+                                   { __float_as_uint(r5.x), __float_as_uint(r5.y) }, { __float_as_uint(r5.z), __float_as_uint(r5.w) } };
+        ref[0] = __float_as_int(r1.x); ref[1] = __float_as_int(r1.y); ref[2] = __float_as_int(r1.z); ref[3] = __float_as_int(r1.w);
+        ref[4] = __float_as_int(r2.x); ref[5] = __float_as_int(r2.y); ref[6] = __float_as_int(r2.z); ref[7] = __float_as_int(r2.w);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int w = c >> 2, sh = 8 * (c & 3);
+            const float4 lo = make_float4(fma_((float)((q[0][w] >> sh) & 0xffu), sx, r0.x), fma_((float)((q[1][w] >> sh) & 0xffu), sy, r0.y),
+                                          fma_((float)((q[2][w] >> sh) & 0xffu), sz, r0.z), 0.f);
+            const float4 hi = make_float4(fma_((float)((q[3][w] >> sh) & 0xffu), sx, r0.x), fma_((float)((q[4][w] >> sh) & 0xffu), sy, r0.y),
+                                          fma_((float)((q[5][w] >> sh) & 0xffu), sz, r0.z), 0.f);
+            float tn;
+            const bool hb = box_test(lo, hi, rs, t_best, tn) && ref[c] != PT_BVH_EMPTY;
+            key[c] = hb ? ((__float_as_uint(tn) & ~7u) | (uint32_t)c) : 0xFFFFFFFFu;
+        }
+    } else if constexpr (L == PT_BVH_WIDTH_4Q) {
         const uint32_t eb = __float_as_uint(r0.w);
         const float sx = __uint_as_float((eb & 0xffu) << 23), sy = __uint_as_float(((eb >> 8) & 0xffu) << 23),
                     sz = __uint_as_float(((eb >> 16) & 0xffu) << 23);
         const uint32_t qlx = __float_as_uint(r2.x), qly = __float_as_uint(r2.y), qlz = __float_as_uint(r2.z),
                        qhx = __float_as_uint(r2.w), qhy = __float_as_uint(r3.x), qhz = __float_as_uint(r3.y);
         ref[0] = __float_as_int(r1.x); ref[1] = __float_as_int(r1.y); ref[2] = __float_as_int(r1.z); ref[3] = __float_as_int(r1.w);
+        // (measured and rejected: the (lo, hi) pairs of this decode + slab test as 24 v_pk_fma_f32 instead of 48 v_fma_f32 —
+        //  bit-identical, but 6 % slower: packed fp32 issues at half rate here and wants aligned register pairs)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float4 lo = make_float4(fma_((float)((qlx >> (8 * c)) & 0xffu), sx, r0.x), fma_((float)((qly >> (8 * c)) & 0xffu), sy, r0.y),
@@ -203,8 +232,13 @@ PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, floa
             const int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
         }
     };
-    if (N == 2) { cswap(0, 1); }
-    else { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); }
+    if constexpr (N == 2) { cswap(0, 1); }
+    else if constexpr (N == 4) { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); }
+    else { // 19-comparator network for 8 keys
+        cswap(0, 1); cswap(2, 3); cswap(4, 5); cswap(6, 7); cswap(0, 2); cswap(1, 3); cswap(4, 6); cswap(5, 7);
+        cswap(1, 2); cswap(5, 6); cswap(0, 4); cswap(3, 7); cswap(1, 5); cswap(2, 6); cswap(1, 4); cswap(3, 6);
+        cswap(2, 4); cswap(3, 5); cswap(3, 4);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,7 +405,7 @@ template <int L, bool COUNT, int FUSE>
 __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(PT_EXT_WAVES(FUSE), PT_EXT_WAVES(FUSE)))) k_extend(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint32_t compact, uint32_t bounces)
 {
     const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u, czero = (it + 2u) % 3u;
-    constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
+    constexpr int N = fanout<L>();
     __shared__ int32_t s_stack[kStackLds * kExtBlock];
     __shared__ uint32_t s_stash[(FUSE != SHADE_NONE ? 5 : 1) * kExtBlock];
     volatile uint32_t *stash = s_stash; // volatile: the values must really leave the registers
@@ -458,8 +492,8 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
             const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 4;
             const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
             if (inner) {
-                uint32_t key[4];
-                int32_t ref[4];
+                uint32_t key[N];
+                int32_t ref[N];
                 visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref); // keys sorted ascending, misses = 0xFFFFFFFF at the end
                 if (COUNT) c_nodes++;
 #pragma unroll
@@ -519,7 +553,7 @@ template <int L, bool COUNT, int FUSE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PACKED_WAVES(FUSE), PT_PACKED_WAVES(FUSE))))
 k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint32_t chunk, uint32_t compact, uint32_t bounces)
 {
-    constexpr int N = (L == PT_BVH_WIDTH_2) ? 2 : 4;
+    constexpr int N = fanout<L>();
     __shared__ int32_t s_stack[kStackLds * 64];
     __shared__ uint32_t s_stash[(FUSE != SHADE_NONE ? 5 : 1) * 64];
     volatile uint32_t *stash = s_stash;
@@ -651,8 +685,8 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
                 const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
                 if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; }
                 else if (inner) {
-                    uint32_t key[4];
-                    int32_t ref[4];
+                    uint32_t key[N];
+                    int32_t ref[N];
                     visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref);
                     if (COUNT) c_nodes++;
 #pragma unroll
@@ -822,6 +856,7 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
     case PT_BVH_WIDTH_2:  count ? extend_lc<PT_BVH_WIDTH_2, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_2, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
     case PT_BVH_WIDTH_4:  count ? extend_lc<PT_BVH_WIDTH_4, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_4, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
     case PT_BVH_WIDTH_4Q: count ? extend_lc<PT_BVH_WIDTH_4Q, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_4Q, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
+    case PT_BVH_WIDTH_8Q: count ? extend_lc<PT_BVH_WIDTH_8Q, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_8Q, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -62,7 +62,7 @@ def test_reference_sphere_ragged_sizes(P, pto, renderer, w, h):
     assert np.array_equal(renderer.ReadFramebuffer(), of) and np.array_equal(renderer.ReadFramebufferRGBA8(), ob)
 
 
-@pytest.mark.parametrize("width", [2, 4, 68])
+@pytest.mark.parametrize("width", [2, 4, 68, 72])
 def test_c1_cornell(P, pto, renderer, width):
     """BASELINE config C1: Cornell box, 4 Lambert spheres + area light, 256x256, 4 spp."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL, 0, 0x5EED0001, 256, 256)
@@ -71,14 +71,14 @@ def test_c1_cornell(P, pto, renderer, width):
     assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests)
 
 
-@pytest.mark.parametrize("width", [2, 4, 68])
+@pytest.mark.parametrize("width", [2, 4, 68, 72])
 def test_c4_glass_metal_depth16(P, pto, renderer, width):
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, 200, 150)
     img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(200, 150, spp=8, max_depth=16), width)
     assert_parity(img, st, ref, ost)
 
 
-@pytest.mark.parametrize("width", [2, 4, 68])
+@pytest.mark.parametrize("width", [2, 4, 68, 72])
 def test_c3_triangle_soup(P, pto, renderer, width):
     sd = P.make_scene(P.native.PT_SCENE_TRIANGLE_SOUP, 50000, 0x5EED0001, 160, 120)
     img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(160, 120, spp=4, max_depth=8), width, count=True)
@@ -140,7 +140,7 @@ def test_4k_frame_and_full_hd_soup(P, pto, renderer):
     assert_parity(img, st, ref, ost)
 
 
-@pytest.mark.parametrize("layout", [2, 4, 68])
+@pytest.mark.parametrize("layout", [2, 4, 68, 72])
 def test_gpu_lbvh_builder(P, pto, renderer, layout):
     """hierarchy built on the GPU (Morton sort + Karras + refit). The blob must pass the oracle's structural
     validator, the HIP frame must equal the oracle traversing THOSE bytes (rays and visit counts included), and — because the
@@ -245,7 +245,7 @@ def test_edge_cases(P, pto, renderer):
     sd = P.SceneData(cam=cam)
     sd.verts = np.array([[-1, -1, 0, 1, -1, 0, 0, 1, 0]], np.float32); sd.tri_mat = np.zeros(1, np.uint32)
     m = np.zeros(1, P.MATERIAL_DTYPE); m["albedo"] = 0.5; m["emission"] = (1, 2, 3); sd.mats = m
-    for width in (2, 4, 68):
+    for width in (2, 4, 68, 72):
         img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(70, 40, spp=1, max_depth=1), width)
         assert_parity(img, st, ref, ost)
         assert st.rays == 70 * 40 and img[..., 0].max() == 1.0

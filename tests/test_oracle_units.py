@@ -119,14 +119,14 @@ def test_oracle_bvh_equals_brute_force(P, pto):
 
 
 @pytest.mark.parametrize("kind,detail", [(0, 0), (1, 0), (2, 5000), (3, 4000)])
-@pytest.mark.parametrize("width", [2, 4, 68])
+@pytest.mark.parametrize("width", [2, 4, 68, 72])
 def test_product_bvh_blob_validates_and_matches_brute_force(P, pto, kind, detail, width):
     """The product's host-side builder (detached scene, no device) against the oracle's structural validator, and the
     oracle traversing those bytes against brute force."""
     from pathtracing_amd.host import build_bvh_detached
     sd = P.make_scene(kind, detail, 3, 64, 64)
     info, nodes, tris = build_bvh_detached(sd, width)
-    assert info.width == width and info.n_tris == len(sd.tri_mat) and info.node_bytes == info.n_nodes * (64 if width == 68 else width * 32)
+    assert info.width == width and info.n_tris == len(sd.tri_mat) and info.node_bytes == info.n_nodes * (64 if width == 68 else 128 if width == 72 else width * 32)
     s = pto.Scene(sd, (width, nodes, tris))
     rc, depth = s.validate_bvh()
     assert rc == 0 and depth == info.max_depth
