@@ -183,15 +183,28 @@ PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, floa
                                    { __float_as_uint(r5.x), __float_as_uint(r5.y) }, { __float_as_uint(r5.z), __float_as_uint(r5.w) } };
         ref[0] = __float_as_int(r1.x); ref[1] = __float_as_int(r1.y); ref[2] = __float_as_int(r1.z); ref[3] = __float_as_int(r1.w);
         ref[4] = __float_as_int(r2.x); ref[5] = __float_as_int(r2.y); ref[6] = __float_as_int(r2.z); ref[7] = __float_as_int(r2.w);
+        // near / far planes picked per axis by the sign of the ray direction, on the packed bytes, once per node: exactly
+        // the values box_test()'s min(ta,tb) / max(ta,tb) would pick (fma is monotone in the plane), for 6 selects per node
+        // instead of 6 min/max per child — the kernel is VALU-issue bound as much as memory bound
+        const bool ng[3] = { rs.inv.x < 0.f, rs.inv.y < 0.f, rs.inv.z < 0.f };
+        const float sc[3] = { sx, sy, sz }, og[3] = { r0.x, r0.y, r0.z }, iv[3] = { rs.inv.x, rs.inv.y, rs.inv.z }, no[3] = { rs.noi.x, rs.noi.y, rs.noi.z };
+        uint32_t qn[3][2], qf[3][2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) { qn[k][w] = ng[k] ? q[3 + k][w] : q[k][w]; qf[k][w] = ng[k] ? q[k][w] : q[3 + k][w]; }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int w = c >> 2, sh = 8 * (c & 3);
-            const float4 lo = make_float4(fma_((float)((q[0][w] >> sh) & 0xffu), sx, r0.x), fma_((float)((q[1][w] >> sh) & 0xffu), sy, r0.y),
-                                          fma_((float)((q[2][w] >> sh) & 0xffu), sz, r0.z), 0.f);
-            const float4 hi = make_float4(fma_((float)((q[3][w] >> sh) & 0xffu), sx, r0.x), fma_((float)((q[4][w] >> sh) & 0xffu), sy, r0.y),
-                                          fma_((float)((q[5][w] >> sh) & 0xffu), sz, r0.z), 0.f);
-            float tn;
-            const bool hb = box_test(lo, hi, rs, t_best, tn) && ref[c] != PT_BVH_EMPTY;
+            float tnk[3], tfk[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                tnk[k] = fma_(fma_((float)((qn[k][w] >> sh) & 0xffu), sc[k], og[k]), iv[k], no[k]);
+                tfk[k] = fma_(fma_((float)((qf[k][w] >> sh) & 0xffu), sc[k], og[k]), iv[k], no[k]);
+            }
+            const float tn = fmax_(fmax_(tnk[0], tnk[1]), fmax_(tnk[2], 0.0f));
+            const float tf = fmin_(fmin_(tfk[0], tfk[1]), fmin_(tfk[2], t_best)) * 1.0000004f;
+            const bool hb = tn <= tf && ref[c] != PT_BVH_EMPTY;
             key[c] = hb ? ((__float_as_uint(tn) & ~7u) | (uint32_t)c) : 0xFFFFFFFFu;
         }
     } else if constexpr (L == PT_BVH_WIDTH_4Q) {
@@ -203,14 +216,24 @@ PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, floa
         ref[0] = __float_as_int(r1.x); ref[1] = __float_as_int(r1.y); ref[2] = __float_as_int(r1.z); ref[3] = __float_as_int(r1.w);
         // (measured and rejected: the (lo, hi) pairs of this decode + slab test as 24 v_pk_fma_f32 instead of 48 v_fma_f32 —
         //  bit-identical, but 6 % slower: packed fp32 issues at half rate here and wants aligned register pairs)
+        // near / far planes by the sign of the ray direction, selected on the packed bytes once per node (see BVH8Q above)
+        const bool ng[3] = { rs.inv.x < 0.f, rs.inv.y < 0.f, rs.inv.z < 0.f };
+        const float sc[3] = { sx, sy, sz }, og[3] = { r0.x, r0.y, r0.z }, iv[3] = { rs.inv.x, rs.inv.y, rs.inv.z }, no[3] = { rs.noi.x, rs.noi.y, rs.noi.z };
+        const uint32_t ql[3] = { qlx, qly, qlz }, qh[3] = { qhx, qhy, qhz };
+        uint32_t qn[3], qf[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { qn[k] = ng[k] ? qh[k] : ql[k]; qf[k] = ng[k] ? ql[k] : qh[k]; }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float4 lo = make_float4(fma_((float)((qlx >> (8 * c)) & 0xffu), sx, r0.x), fma_((float)((qly >> (8 * c)) & 0xffu), sy, r0.y),
-                                          fma_((float)((qlz >> (8 * c)) & 0xffu), sz, r0.z), 0.f);
-            const float4 hi = make_float4(fma_((float)((qhx >> (8 * c)) & 0xffu), sx, r0.x), fma_((float)((qhy >> (8 * c)) & 0xffu), sy, r0.y),
-                                          fma_((float)((qhz >> (8 * c)) & 0xffu), sz, r0.z), 0.f);
-            float tn;
-            const bool hb = box_test(lo, hi, rs, t_best, tn) && ref[c] != PT_BVH_EMPTY;
+            float tnk[3], tfk[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                tnk[k] = fma_(fma_((float)((qn[k] >> (8 * c)) & 0xffu), sc[k], og[k]), iv[k], no[k]);
+                tfk[k] = fma_(fma_((float)((qf[k] >> (8 * c)) & 0xffu), sc[k], og[k]), iv[k], no[k]);
+            }
+            const float tn = fmax_(fmax_(tnk[0], tnk[1]), fmax_(tnk[2], 0.0f));
+            const float tf = fmin_(fmin_(tfk[0], tfk[1]), fmin_(tfk[2], t_best)) * 1.0000004f;
+            const bool hb = tn <= tf && ref[c] != PT_BVH_EMPTY;
             key[c] = hb ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
         }
     } else {
