@@ -421,6 +421,9 @@ PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint
 // Occupancy is worth more to this kernel than a few spills: it hides the latency of divergent node gathers with waves, and
 // unconstrained the fused variants take 84-89 VGPRs (5 waves/SIMD). Measured on the 1M-triangle Cornell box (Mrays/s):
 // 5 waves 9555, 6 waves 10326, 7 waves 10849 (SGPR spills only); the all-kinds variant spills 9 VGPRs at 7 and prefers 6.
+#ifndef PT_WHILE_WHILE
+#define PT_WHILE_WHILE 1
+#endif
 #ifndef PT_EXT_WAVES
 #define PT_EXT_WAVES(FUSE) ((FUSE) == SHADE_INLINE ? 6 : 7)
 #endif
@@ -507,6 +510,57 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
             return sp < kStackLds ? s_stack[sp * kExtBlock + tid] : ps.stack_ovf[(size_t)(sp - kStackLds) * ovf_stride + uid];
         };
 
+#if PT_WHILE_WHILE
+        // while-while: a lane that reaches a leaf waits at the reconvergence point of the node loop until every lane of
+        // the wave is at a leaf or done; then the leaves are tested together. Each lane still makes exactly the visits,
+        // in exactly the order, of docs/SPEC.md §4.1 (only the interleaving across lanes changes), so hits and visit
+        // counters are the oracle's. Why: with one loop for both kinds of step the wave issued the ~160-instruction node
+        // code AND the ~125-instruction triangle code in practically every iteration, the latter for ~1 lane in 8; the
+        // kernel is VALU-issue bound (rocprofv3: 34 % of wave time waits for an issue slot, 43 % of VALU lanes active).
+        for (;;) {
+            while ((uint32_t)cur < (uint32_t)PT_BVH_EMPTY) { // ---- node phase: inner-node refs are 0 .. 0x7ffffffe (EMPTY = 0x7fffffff)
+                if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; break; }
+                const float4 *base = sc.nodes + (size_t)cur * node_rows<L>();
+                const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
+                const bool deep = __any((int)(sp + (uint32_t)(N - 1) > kStackLds)) != 0; // stack fast path, see below
+                uint32_t key[N];
+                int32_t ref[N];
+                visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref); // keys sorted ascending, misses = 0xFFFFFFFF at the end
+                if (COUNT) c_nodes++;
+                if (!deep) {
+#pragma unroll
+                    for (int i = N - 1; i >= 1; --i) { // farthest first, nearest stays in `cur`
+                        s_stack[sp * kExtBlock + tid] = ref[i];
+                        sp += key[i] != 0xFFFFFFFFu ? 1u : 0u;
+                    }
+                    if (key[0] != 0xFFFFFFFFu) cur = ref[0];
+                    else if (sp) { --sp; cur = s_stack[sp * kExtBlock + tid]; }
+                    else cur = PT_BVH_EMPTY;
+                } else {
+#pragma unroll
+                    for (int i = N - 1; i >= 1; --i)
+                        if (key[i] != 0xFFFFFFFFu) push(ref[i]);
+                    cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop();
+                }
+            }
+            if (cur == PT_BVH_EMPTY) break;
+            { // ---- leaf phase: its triangles in array order
+                const uint32_t enc = (uint32_t)~cur;
+                uint32_t first = enc >> 3, more = enc & 7u;
+                for (;;) {
+                    const float4 *base = sc.tris + (size_t)first * 4;
+                    const float4 r0 = base[0], r1 = base[1], r2 = base[2];
+                    tri_test(r0, r1, r2, first, o, d, h);
+                    if (COUNT) c_tris++;
+                    if (more == 0u) break;
+                    ++first; --more;
+                }
+                const bool deep = __any((int)(sp > kStackLds)) != 0;
+                if (!deep) { if (sp) { --sp; cur = s_stack[sp * kExtBlock + tid]; } else cur = PT_BVH_EMPTY; }
+                else cur = pop();
+            }
+        }
+#else
         while (cur != PT_BVH_EMPTY) {
             if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); break; }
             // one fetch for both kinds of step: 4 rows from the node, or from the first triangle of the leaf
@@ -514,21 +568,42 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
             const uint32_t enc = (uint32_t)~cur, first = enc >> 3, more = enc & 7u; // leaf: `more` triangles after this one
             const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 4;
             const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
+            // Stack fast path. While every lane of the wave still has room for a whole node's pushes in its LDS column (the
+            // common case), a push is an unconditional LDS store plus a predicated increment and a pop is a plain LDS load —
+            // no LDS-or-spill branch per push. (The branching version was 76 of the ~340 instructions of a loop iteration,
+            // and the kernel is VALU-issue bound.) The spilling code runs only when some lane is near the end of its column.
+            const bool deep = __any((int)(sp + (uint32_t)(N - 1) > kStackLds)) != 0;
+            auto pop_fast = [&]() -> int32_t {
+                if (sp == 0) return PT_BVH_EMPTY;
+                --sp;
+                return s_stack[sp * kExtBlock + tid];
+            };
             if (inner) {
                 uint32_t key[N];
                 int32_t ref[N];
                 visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref); // keys sorted ascending, misses = 0xFFFFFFFF at the end
                 if (COUNT) c_nodes++;
+                if (!deep) {
 #pragma unroll
-                for (int i = N - 1; i >= 1; --i)
-                    if (key[i] != 0xFFFFFFFFu) push(ref[i]); // farthest first, nearest stays in `cur`
-                cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop();
+                    for (int i = N - 1; i >= 1; --i) { // farthest first, nearest stays in `cur`
+                        s_stack[sp * kExtBlock + tid] = ref[i];
+                        sp += key[i] != 0xFFFFFFFFu ? 1u : 0u;
+                    }
+                    cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop_fast();
+                } else {
+#pragma unroll
+                    for (int i = N - 1; i >= 1; --i)
+                        if (key[i] != 0xFFFFFFFFu) push(ref[i]);
+                    cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop();
+                }
             } else {
                 tri_test(r0, r1, r2, first, o, d, h);
                 if (COUNT) c_tris++;
-                cur = more ? (int32_t)~(((first + 1u) << 3) | (more - 1u)) : pop(); // rest of the leaf, in array order
+                // rest of the leaf, in array order
+                cur = more ? (int32_t)~(((first + 1u) << 3) | (more - 1u)) : (deep ? pop() : pop_fast());
             }
         }
+#endif
 
         if (FUSE == SHADE_NONE) ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref)); // k_shade walks the same queue in the same order
         else {
@@ -706,20 +781,35 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
                 const uint32_t enc = (uint32_t)~cur, first = enc >> 3, more = enc & 7u;
                 const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 4;
                 const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
+                const bool deep = __any((int)(sp + (uint32_t)(N - 1) > kStackLds)) != 0; // stack fast path as in k_extend
+                auto pop_fast = [&]() -> int32_t {
+                    if (sp == 0) return PT_BVH_EMPTY;
+                    --sp;
+                    return s_stack[sp * 64u + lane];
+                };
                 if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; }
                 else if (inner) {
                     uint32_t key[N];
                     int32_t ref[N];
                     visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref);
                     if (COUNT) c_nodes++;
+                    if (!deep) {
 #pragma unroll
-                    for (int i = N - 1; i >= 1; --i)
-                        if (key[i] != 0xFFFFFFFFu) push(ref[i]);
-                    cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop();
+                        for (int i = N - 1; i >= 1; --i) {
+                            s_stack[sp * 64u + lane] = ref[i];
+                            sp += key[i] != 0xFFFFFFFFu ? 1u : 0u;
+                        }
+                        cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop_fast();
+                    } else {
+#pragma unroll
+                        for (int i = N - 1; i >= 1; --i)
+                            if (key[i] != 0xFFFFFFFFu) push(ref[i]);
+                        cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop();
+                    }
                 } else {
                     tri_test(r0, r1, r2, first, o, d, h);
                     if (COUNT) c_tris++;
-                    cur = more ? (int32_t)~(((first + 1u) << 3) | (more - 1u)) : pop();
+                    cur = more ? (int32_t)~(((first + 1u) << 3) | (more - 1u)) : (deep ? pop() : pop_fast());
                 }
             }
             const uint32_t busy = (uint32_t)__popcll(__ballot(has && cur != PT_BVH_EMPTY));
