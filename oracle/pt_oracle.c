@@ -250,11 +250,28 @@ static void closest_hit(const pto_scene *s, v3 o, v3 d, hit_t *h, pto_stats *st)
             const uint32_t slot_mask = N > 4 ? 7u : 3u; /* low key bits that carry the slot index (SPEC §4.2) */
             st->node_visits++;
             uint32_t keys[8]; int32_t refs[8]; int nh = 0;
+            /* quantised layouts (SPEC §4.1): the slab distances come straight from the bytes, t = fma(q, A, B) with
+             * A = 2^e * inv (exact) and B = fma(origin, inv, noi) per axis and node */
+            const int quant = s->bvh_width == PTO_BVH_LAYOUT_4Q || s->bvh_width == PTO_BVH_LAYOUT_8Q;
+            const uint8_t *raw = NULL; float qa[3] = { 0, 0, 0 }, qb[3] = { 0, 0, 0 };
+            if (quant) {
+                raw = (const uint8_t *)s->nodes + (size_t)ref * (N == 8 ? 128 : 64);
+                float org[3]; memcpy(org, raw, 12);
+                for (int k = 0; k < 3; ++k) { qa[k] = bits2f((uint32_t)raw[12 + k] << 23) * inv[k]; qb[k] = fma_(org[k], inv[k], noi[k]); }
+            }
             for (uint32_t c = 0; c < N; ++c) {
                 if (nd[c].ref == PTO_BVH_EMPTY) continue;
-                float tax = fma_(nd[c].lo[0], inv[0], noi[0]), tbx = fma_(nd[c].hi[0], inv[0], noi[0]);
-                float tay = fma_(nd[c].lo[1], inv[1], noi[1]), tby = fma_(nd[c].hi[1], inv[1], noi[1]);
-                float taz = fma_(nd[c].lo[2], inv[2], noi[2]), tbz = fma_(nd[c].hi[2], inv[2], noi[2]);
+                float tax, tbx, tay, tby, taz, tbz;
+                if (quant) {
+                    const uint8_t *ql = raw + 16 + 4 * N, *qh = ql + 3 * N; /* qlo_x[N], qlo_y[N], qlo_z[N], then qhi_* */
+                    tax = fma_((float)ql[c], qa[0], qb[0]);         tbx = fma_((float)qh[c], qa[0], qb[0]);
+                    tay = fma_((float)ql[N + c], qa[1], qb[1]);     tby = fma_((float)qh[N + c], qa[1], qb[1]);
+                    taz = fma_((float)ql[2 * N + c], qa[2], qb[2]); tbz = fma_((float)qh[2 * N + c], qa[2], qb[2]);
+                } else {
+                    tax = fma_(nd[c].lo[0], inv[0], noi[0]); tbx = fma_(nd[c].hi[0], inv[0], noi[0]);
+                    tay = fma_(nd[c].lo[1], inv[1], noi[1]); tby = fma_(nd[c].hi[1], inv[1], noi[1]);
+                    taz = fma_(nd[c].lo[2], inv[2], noi[2]); tbz = fma_(nd[c].hi[2], inv[2], noi[2]);
+                }
                 float tn = max_(max_(min_(tax, tbx), min_(tay, tby)), max_(min_(taz, tbz), 0.0f));
                 float tf = min_(min_(max_(tax, tbx), max_(tay, tby)), min_(max_(taz, tbz), h->t)) * 1.0000004f;
                 if (tn <= tf) { keys[nh] = (f2bits(tn) & ~slot_mask) | c; refs[nh] = nd[c].ref; nh++; }

@@ -184,10 +184,13 @@ PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, floa
         ref[0] = __float_as_int(r1.x); ref[1] = __float_as_int(r1.y); ref[2] = __float_as_int(r1.z); ref[3] = __float_as_int(r1.w);
         ref[4] = __float_as_int(r2.x); ref[5] = __float_as_int(r2.y); ref[6] = __float_as_int(r2.z); ref[7] = __float_as_int(r2.w);
         // near / far planes picked per axis by the sign of the ray direction, on the packed bytes, once per node: exactly
-        // the values box_test()'s min(ta,tb) / max(ta,tb) would pick (fma is monotone in the plane), for 6 selects per node
+        // the values min(ta,tb) / max(ta,tb) of the spec's slab test would pick (fma is monotone in q), for 6 selects per node
         // instead of 6 min/max per child — the kernel is VALU-issue bound as much as memory bound
         const bool ng[3] = { rs.inv.x < 0.f, rs.inv.y < 0.f, rs.inv.z < 0.f };
-        const float sc[3] = { sx, sy, sz }, og[3] = { r0.x, r0.y, r0.z }, iv[3] = { rs.inv.x, rs.inv.y, rs.inv.z }, no[3] = { rs.noi.x, rs.noi.y, rs.noi.z };
+        // docs/SPEC.md §4.1 slab test of a quantised child: t = fma(q, A, B) with A = 2^e * inv (exact: a power of two times inv)
+        // and B = fma(origin, inv, noi) per axis and node — one fma per plane instead of decode + slab
+        const float qa[3] = { sx * rs.inv.x, sy * rs.inv.y, sz * rs.inv.z };
+        const float qb[3] = { fma_(r0.x, rs.inv.x, rs.noi.x), fma_(r0.y, rs.inv.y, rs.noi.y), fma_(r0.z, rs.inv.z, rs.noi.z) };
         uint32_t qn[3][2], qf[3][2];
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -199,8 +202,8 @@ PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, floa
             float tnk[3], tfk[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                tnk[k] = fma_(fma_((float)((qn[k][w] >> sh) & 0xffu), sc[k], og[k]), iv[k], no[k]);
-                tfk[k] = fma_(fma_((float)((qf[k][w] >> sh) & 0xffu), sc[k], og[k]), iv[k], no[k]);
+                tnk[k] = fma_((float)((qn[k][w] >> sh) & 0xffu), qa[k], qb[k]);
+                tfk[k] = fma_((float)((qf[k][w] >> sh) & 0xffu), qa[k], qb[k]);
             }
             const float tn = fmax_(fmax_(tnk[0], tnk[1]), fmax_(tnk[2], 0.0f));
             const float tf = fmin_(fmin_(tfk[0], tfk[1]), fmin_(tfk[2], t_best)) * 1.0000004f;
@@ -218,7 +221,10 @@ PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, floa
         //  bit-identical, but 6 % slower: packed fp32 issues at half rate here and wants aligned register pairs)
         // near / far planes by the sign of the ray direction, selected on the packed bytes once per node (see BVH8Q above)
         const bool ng[3] = { rs.inv.x < 0.f, rs.inv.y < 0.f, rs.inv.z < 0.f };
-        const float sc[3] = { sx, sy, sz }, og[3] = { r0.x, r0.y, r0.z }, iv[3] = { rs.inv.x, rs.inv.y, rs.inv.z }, no[3] = { rs.noi.x, rs.noi.y, rs.noi.z };
+        // docs/SPEC.md §4.1 slab test of a quantised child: t = fma(q, A, B) with A = 2^e * inv (exact: a power of two times inv)
+        // and B = fma(origin, inv, noi) per axis and node — one fma per plane instead of decode + slab
+        const float qa[3] = { sx * rs.inv.x, sy * rs.inv.y, sz * rs.inv.z };
+        const float qb[3] = { fma_(r0.x, rs.inv.x, rs.noi.x), fma_(r0.y, rs.inv.y, rs.noi.y), fma_(r0.z, rs.inv.z, rs.noi.z) };
         const uint32_t ql[3] = { qlx, qly, qlz }, qh[3] = { qhx, qhy, qhz };
         uint32_t qn[3], qf[3];
 #pragma unroll
@@ -228,8 +234,8 @@ PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, floa
             float tnk[3], tfk[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                tnk[k] = fma_(fma_((float)((qn[k] >> (8 * c)) & 0xffu), sc[k], og[k]), iv[k], no[k]);
-                tfk[k] = fma_(fma_((float)((qf[k] >> (8 * c)) & 0xffu), sc[k], og[k]), iv[k], no[k]);
+                tnk[k] = fma_((float)((qn[k] >> (8 * c)) & 0xffu), qa[k], qb[k]);
+                tfk[k] = fma_((float)((qf[k] >> (8 * c)) & 0xffu), qa[k], qb[k]);
             }
             const float tn = fmax_(fmax_(tnk[0], tnk[1]), fmax_(tnk[2], 0.0f));
             const float tf = fmin_(fmin_(tfk[0], tfk[1]), fmin_(tfk[2], t_best)) * 1.0000004f;
