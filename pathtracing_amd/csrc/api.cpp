@@ -71,7 +71,9 @@ struct pt_context {
                                                 // 4.11 -> 3.81 ms, 1/4 7.14 -> 6.62 ms; four loops are slower, the host cannot feed them).
                                                 // Big frames (the 1-GPU headline: 16.6 M slots) keep one loop: the gain is 3 % there, and a
                                                 // launch timed by HIP events, by rocprofv3 and in the benchmark frame stays one and the same thing
-    uint32_t bounces = 4;                       // PTRT_BOUNCES (1..64): path vertices per launch of the fused kernel (state in registers)
+    uint32_t bounces = 0;                       // PTRT_BOUNCES (1..64): path vertices per launch of the fused kernel (state in registers);
+                                                // 0 = max_depth / 2 clamped to [4, 8] (measured: depth 8 -> 4 is best, 12.9 vs 12.3 Grays/s at 8;
+                                                // depth 16 with glass -> 8 is best, 23.0 vs 20.6 at 4)
     double compact_below = 0.9;                // PTRT_COMPACT overrides: a shard re-packs its queue in an iteration that starts with
                                                 // alive/length below this (>1 = every iteration, 0 = never); else carried in place.
                                                 // Measured (1M-tri Cornell): 1080p/64spp 0.75: 10786, 0.9: 11190, always: 11354 Mrays/s;
@@ -581,7 +583,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
             const bool fused = !split_kernels;
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
             HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, use_packed ? packed_chunk : 0u, fused ? shade_mode : -1, compact,
-                                     c->bounces));
+                                     c->bounces ? c->bounces : std::min(8u, std::max(4u, p->max_depth / 2u))));
             if (profile) HIP_TRY(c, hipEventRecord(e1, L.stream));
             if (!fused && !bucket_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, it, L.bound, shade_mode, compact));
             else if (!fused) {
