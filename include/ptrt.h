@@ -124,7 +124,8 @@ typedef struct {
     double other_ms;        /* generate / resolve kernels */
     uint64_t reserved[4];   /* diagnostics: [0] extend kernel in use (1 one ray per lane, 2 lane-packing, 0 unprobed),
                                [1] iterations that re-packed their queues, [2] path states loaded+stored by the loop
-                               (sum over iterations of the paths alive at its start), [3] 0 */
+                               (sum over iterations of the paths alive at its start), [3] with PT_FLAG_COUNT_VISITS: wave-level
+                               iterations of k_extend's node loop (node_visits / (64 * [3]) = lane utilisation of that loop) */
 } pt_stats;
 
 typedef struct {

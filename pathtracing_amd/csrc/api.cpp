@@ -654,6 +654,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     out.gpu_ms = ms;
     out.node_visits = u64_at(kCntNodes); out.tri_tests = u64_at(kCntTris); out.sphere_tests = u64_at(kCntSph);
+    out.reserved[3] = u64_at(kCntWaveNodeIters); // PT_FLAG_COUNT_VISITS + one-ray-per-lane kernel: wave-level node-loop iterations
     out.iterations = iters; out.extend_launches = iters;
     out.reserved[0] = ext_choice; // extend kernel in use at frame end: 1 = one ray per lane, 2 = lane-packing, 0 = frame too short to probe
     out.reserved[1] = hc[kCntCompactions]; // (shard, iteration) pairs that re-packed their queue (the others carried it over in place)

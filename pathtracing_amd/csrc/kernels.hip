@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     const bool active = slot != kInvalidSlot;                  // holes: paths that ended since the queue was last compacted
     const size_t uid = qbase + gid;                            // unique per thread of this launch
 
-    unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0;
+    unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0, c_wave_iters = 0;
     PathRegs r;
     r.o = v3(0.f, 0.f, 0.f); r.d = v3(0.f, 0.f, 1.f); r.T = v3(0.f, 0.f, 0.f); r.key = r.sample = r.depth = 0u;
     if (active) {
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
                 uint32_t key[N];
                 int32_t ref[N];
                 visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref); // keys sorted ascending, misses = 0xFFFFFFFF at the end
-                if (COUNT) c_nodes++;
+                if (COUNT) { c_nodes++; if (lane_id() == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) c_wave_iters++; } // one lane per wave-iteration
                 if (!deep) {
 #pragma unroll
                     for (int i = N - 1; i >= 1; --i) { // farthest first, nearest stays in `cur`
@@ -623,6 +623,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     }
     }
     if (COUNT && active) {
+        if (c_wave_iters) atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntWaveNodeIters), c_wave_iters);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);

@@ -38,6 +38,7 @@ constexpr uint32_t kCntGlobals = kCntRays + kShards * kCounterStride;
 constexpr uint32_t kCntError = kCntGlobals + 0;
 constexpr uint32_t kCntNodes = kCntGlobals + 2, kCntTris = kCntGlobals + 4, kCntSph = kCntGlobals + 6; // u64 each
 constexpr uint32_t kCntCompactions = kCntGlobals + 8; // (shard, iteration) pairs that re-packed their queue
+constexpr uint32_t kCntWaveNodeIters = kCntGlobals + 10; // u64, PT_FLAG_COUNT_VISITS: iterations of the wave-level node loop of k_extend
 constexpr uint32_t kCntTotalWords = kCntGlobals + 16;
 
 // An extend queue has LEN entries of which ALIVE hold a slot; the rest are kInvalidSlot holes left by paths that ended
