@@ -654,7 +654,8 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     out.gpu_ms = ms;
     out.node_visits = u64_at(kCntNodes); out.tri_tests = u64_at(kCntTris); out.sphere_tests = u64_at(kCntSph);
-    out.reserved[3] = u64_at(kCntWaveNodeIters); // PT_FLAG_COUNT_VISITS + one-ray-per-lane kernel: wave-level node-loop iterations
+    // PT_FLAG_COUNT_VISITS + one-ray-per-lane kernel: wave-level node-loop iterations (low 40 bits), of which after the wave's first leaf phase (high 24 bits, in units of 2^16... no: plain count >> 0, packed at bit 40)
+    out.reserved[3] = (u64_at(kCntWaveNodeIters) & 0xFFFFFFFFFFull) | (u64_at(kCntWaveNodeIters + 2) << 40);
     out.iterations = iters; out.extend_launches = iters;
     out.reserved[0] = ext_choice; // extend kernel in use at frame end: 1 = one ray per lane, 2 = lane-packing, 0 = frame too short to probe
     out.reserved[1] = hc[kCntCompactions]; // (shard, iteration) pairs that re-packed their queue (the others carried it over in place)

@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     const bool active = slot != kInvalidSlot;                  // holes: paths that ended since the queue was last compacted
     const size_t uid = qbase + gid;                            // unique per thread of this launch
 
-    unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0, c_wave_iters = 0;
+    unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0, c_wave_iters = 0, c_wave_iters_late = 0;
     PathRegs r;
     r.o = v3(0.f, 0.f, 0.f); r.d = v3(0.f, 0.f, 1.f); r.T = v3(0.f, 0.f, 0.f); r.key = r.sample = r.depth = 0u;
     if (active) {
@@ -523,6 +523,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
         // counters are the oracle's. Why: with one loop for both kinds of step the wave issued the ~160-instruction node
         // code AND the ~125-instruction triangle code in practically every iteration, the latter for ~1 lane in 8; the
         // kernel is VALU-issue bound (rocprofv3: 34 % of wave time waits for an issue slot, 43 % of VALU lanes active).
+        bool late_cycle = false; // (COUNT diagnostics) set once this wave has run a leaf phase for the current rays
         for (;;) {
             while ((uint32_t)cur < (uint32_t)PT_BVH_EMPTY) { // ---- node phase: inner-node refs are 0 .. 0x7ffffffe (EMPTY = 0x7fffffff)
                 if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; break; }
@@ -532,7 +533,10 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
                 uint32_t key[N];
                 int32_t ref[N];
                 visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref); // keys sorted ascending, misses = 0xFFFFFFFF at the end
-                if (COUNT) { c_nodes++; if (lane_id() == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) c_wave_iters++; } // one lane per wave-iteration
+                if (COUNT) { // one lane per wave-iteration counts it; [1]: iterations after the wave's first leaf phase of this ray
+                    c_nodes++;
+                    if (lane_id() == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) { c_wave_iters++; if (late_cycle) c_wave_iters_late++; }
+                }
                 if (!deep) {
 #pragma unroll
                     for (int i = N - 1; i >= 1; --i) { // farthest first, nearest stays in `cur`
@@ -551,6 +555,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
             }
             if (cur == PT_BVH_EMPTY) break;
             { // ---- leaf phase: its triangles in array order
+                if (COUNT) late_cycle = true;
                 const uint32_t enc = (uint32_t)~cur;
                 uint32_t first = enc >> 3, more = enc & 7u;
                 for (;;) {
@@ -624,6 +629,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     }
     if (COUNT && active) {
         if (c_wave_iters) atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntWaveNodeIters), c_wave_iters);
+        if (c_wave_iters_late) atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntWaveNodeIters + 2), c_wave_iters_late);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);

@@ -9,9 +9,10 @@ r = P.Renderer(P.Window(W, H)); r.Init()
 for name in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["tess"]):
     kind, detail, depth = cfg[name]
     r.SetScene(P.make_scene(kind, detail, 0x5EED0001, W, H), 0)
-    r.Params = P.make_params(W, H, spp=8, max_depth=depth, streams=8, flags=N.PT_FLAG_COUNT_VISITS | N.PT_FLAG_EXTEND_SIMPLE)
+    r.Params = P.make_params(W, H, spp=64, max_depth=depth, streams=8, flags=N.PT_FLAG_COUNT_VISITS | N.PT_FLAG_EXTEND_SIMPLE)
     st = r.Render(0.0)
-    it = int(st.reserved[3])
+    it = int(st.reserved[3]) & 0xFFFFFFFFFF; late = int(st.reserved[3]) >> 40
     print(f"{name}: rays {st.rays/1e6:.1f}M nodes/ray {st.node_visits/st.rays:.2f} wave node-loop iterations {it/1e6:.2f}M "
-          f"-> {it*64/st.rays:.2f} lane-slots per ray, node-loop lane utilisation {st.node_visits/(64*it):.3f}", flush=True)
+          f"-> {it*64/st.rays:.2f} lane-slots per ray, node-loop lane utilisation {st.node_visits/(64*it):.3f}; "
+          f"iterations after a wave's first leaf phase: {late/max(it,1):.2%}", flush=True)
 r.Dispose()
