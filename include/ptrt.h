@@ -125,7 +125,8 @@ typedef struct {
     uint64_t reserved[4];   /* diagnostics: [0] extend kernel in use (1 one ray per lane, 2 lane-packing, 0 unprobed),
                                [1] iterations that re-packed their queues, [2] path states loaded+stored by the loop
                                (sum over iterations of the paths alive at its start), [3] with PT_FLAG_COUNT_VISITS: wave-level
-                               iterations of k_extend's node loop (node_visits / (64 * [3]) = lane utilisation of that loop) */
+                               iterations of k_extend's node loop in bits 0-39 (node_visits / (64 * that) = lane utilisation of the
+                               loop), those after the wave's first leaf phase from bit 40 up */
 } pt_stats;
 
 typedef struct {

@@ -654,7 +654,8 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     out.gpu_ms = ms;
     out.node_visits = u64_at(kCntNodes); out.tri_tests = u64_at(kCntTris); out.sphere_tests = u64_at(kCntSph);
-    // PT_FLAG_COUNT_VISITS + one-ray-per-lane kernel: wave-level node-loop iterations (low 40 bits), of which after the wave's first leaf phase (high 24 bits, in units of 2^16... no: plain count >> 0, packed at bit 40)
+    // PT_FLAG_COUNT_VISITS + one-ray-per-lane kernel: wave-level node-loop iterations (bits 0-39) and, from bit 40 up, how many
+    // of them came after the wave's first leaf phase of the ray (diagnostic for tools/exp_util.py)
     out.reserved[3] = (u64_at(kCntWaveNodeIters) & 0xFFFFFFFFFFull) | (u64_at(kCntWaveNodeIters + 2) << 40);
     out.iterations = iters; out.extend_launches = iters;
     out.reserved[0] = ext_choice; // extend kernel in use at frame end: 1 = one ray per lane, 2 = lane-packing, 0 = frame too short to probe
