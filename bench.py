@@ -102,6 +102,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    recv = None  # rank 0's receive buffer for the gather, allocated once
+    if world > 1 and rank == 0 and not args.rehearse_gloo:
+        recv = torch.empty(world * per_rank, dtype=torch.float32, device="cuda")
+
     def step():
         st = r.Render(0.0)  # synchronous: all kernels of this rank's tiles are done on return
         if world > 1:
@@ -110,7 +114,7 @@ def main():
                 got = gather_tiles(mine.cpu(), per_rank, rank, world, dist)
                 got = got.cuda() if rank == 0 else None
             else:
-                got = gather_tiles(mine, per_rank, rank, world, dist)  # the one exchange step: tile radiance to rank 0 over xGMI
+                got = gather_tiles(mine, per_rank, rank, world, dist, out=recv)  # the one exchange step: tile radiance to rank 0 over xGMI
             if rank == 0:
                 torch.cuda.synchronize()
                 r.AssembleTiles(got.data_ptr(), got.numel())

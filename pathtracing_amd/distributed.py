@@ -21,14 +21,20 @@ def slot_to_pixel(slot, rank, nranks, tiles_x):
     return x, y, tile
 
 
-def gather_tiles(local_tiles, per_rank_floats, rank, world, dist=None, dst=0):
+def gather_tiles(local_tiles, per_rank_floats, rank, world, dist=None, dst=0, out=None):
     """Gather every rank's tile-major buffer (1-D float32 tensor of per_rank_floats) to `dst`.
-    Returns the concatenated [world * per_rank_floats] tensor on dst, None elsewhere."""
+    Returns the concatenated [world * per_rank_floats] tensor on dst, None elsewhere. `out`: a receive buffer of
+    world * per_rank_floats elements to reuse on dst (a frame loop allocates it once)."""
     import torch
     if world == 1:
         return local_tiles
     assert local_tiles.numel() == per_rank_floats
-    out = torch.empty(world * per_rank_floats, dtype=local_tiles.dtype, device=local_tiles.device) if rank == dst else None
-    glist = list(out.split(per_rank_floats)) if rank == dst else None
+    if rank == dst:
+        if out is None:
+            out = torch.empty(world * per_rank_floats, dtype=local_tiles.dtype, device=local_tiles.device)
+        assert out.numel() == world * per_rank_floats and out.device == local_tiles.device and out.dtype == local_tiles.dtype
+        glist = list(out.split(per_rank_floats))
+    else:
+        out, glist = None, None
     dist.gather(local_tiles, glist, dst=dst)
     return out
