@@ -120,6 +120,13 @@ class Scene:
         self.set_bvh(2, nb, tb)
         return nb, tb
 
+    def closest(self, o, d):
+        """(primitive id or 0xFFFFFFFF, t) of the closest hit of one ray (SPEC §4)."""
+        t = C.c_float()
+        pid = lib.pto_closest(C.byref(self.c), (C.c_float * 3)(*[float(x) for x in o]), (C.c_float * 3)(*[float(x) for x in d]),
+                              C.byref(t), None)
+        return int(pid), float(t.value)
+
     def validate_bvh(self):
         d = C.c_uint32()
         rc = lib.pto_bvh_validate(self.c.bvh_width, self.c.n_nodes, self.c.nodes, self.c.tris48, self.c.n_tris,

@@ -175,3 +175,48 @@ def test_threads_do_not_change_the_image(P, pto):
     a, _ = pto.render(pto.Scene(sd), p, threads=1)
     b, _ = pto.render(pto.Scene(sd), p, threads=4)
     assert np.array_equal(a, b)
+
+
+def test_default_layout_follows_scene_size(P, pto):
+    """PT_BVH_WIDTH_DEFAULT: BVH8Q for scenes of at most 256 triangles (a node or two, fewer dependent steps), BVH4Q above.
+    Either way the blob validates and the oracle traversing it equals brute force (the quantised slab test of SPEC §4.1)."""
+    from pathtracing_amd.host import build_bvh_detached
+    for kind, detail, want in ((P.native.PT_SCENE_CORNELL, 0, 72), (P.native.PT_SCENE_CORNELL_TESS, 3000, 68)):
+        sd = P.make_scene(kind, detail, 5, 48, 48)
+        info, nodes, tris = build_bvh_detached(sd, 0)
+        assert info.width == want, (len(sd.tri_mat), info.width)
+        s = pto.Scene(sd, (info.width, nodes, tris))
+        assert s.validate_bvh()[0] == 0
+        p = P.make_params(48, 48, spp=2, max_depth=4)
+        a, sa = pto.render(s, p)
+        b, sb = pto.render(pto.Scene(sd), p)
+        assert sa.rays == sb.rays and np.array_equal(a, b)
+
+
+def test_quantised_slab_test_is_conservative_on_grazing_rays(P, pto):
+    """SPEC §4.1 folds the dequantisation into the slab test. Rays that graze box faces and run along axes (zero direction
+    components, origins on node planes) are where a non-conservative plane would lose a hit: every layout must return
+    exactly the brute-force closest hit."""
+    from pathtracing_amd.host import build_bvh_detached
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_TESS, 5000, 11, 32, 32)
+    rng = np.random.default_rng(7)
+    v = sd.verts.reshape(-1, 3, 3)
+    rays = []
+    for _ in range(300):
+        t = v[rng.integers(len(v))]
+        target = t[0] if rng.random() < 0.5 else (t[0] + t[1]) * 0.5          # a vertex or an edge midpoint
+        o = np.array([0.0, 0.0, 0.0], np.float32) + rng.uniform(-0.3, 0.3, 3).astype(np.float32)
+        if rng.random() < 0.3:
+            o[rng.integers(3)] = target[rng.integers(3)]                       # origin in an axis plane of the target
+        d = (target - o).astype(np.float32)
+        if rng.random() < 0.3:
+            d[rng.integers(3)] = 0.0                                           # axis-parallel component
+        n = float(np.linalg.norm(d))
+        if n > 1e-6:
+            rays.append((o, (d / n).astype(np.float32)))
+    brute = pto.Scene(sd)
+    for width in (2, 4, 68, 72):
+        info, nodes, tris = build_bvh_detached(sd, width)
+        s = pto.Scene(sd, (width, nodes, tris))
+        for o, d in rays:
+            assert s.closest(o, d) == brute.closest(o, d)
