@@ -21,7 +21,8 @@ constexpr uint32_t kExtBlock = PT_EXT_BLOCK;       // workgroup size of k_extend
 constexpr uint32_t kMaxSpheres = 64;
 
 // Queue sharding. A slot belongs to shard (slot >> 8) % kShards for the whole frame, every queue is kShards
-// independent regions of `shard_cap` entries with one counter each, and blockIdx.y selects the shard in every kernel.
+// independent regions of `shard_cap` entries with one counter line each, and a workgroup works on exactly one shard
+// (kernels.hip block_pos: 1-D grids with the shard as the fastest index).
 // Why: a queue push is one returning atomic per wavefront; on ONE address that saturates at ~88 atomics/us
 // (MI355X_MICROARCH.md "dequeue"), which made both wavefront kernels atomic-bound (~230 us per launch regardless of
 // the scene). 64 counters on 64 separate lines take the same pushes at ~64x the rate.
@@ -81,7 +82,7 @@ struct PathState {           // SoA over slots
     uint32_t stack_ovf_entries;
     uint32_t n_slots;
     uint32_t shard_cap;      // entries per shard region = slots owned by a shard (multiple of 256)
-    uint32_t shard_base, shard_count; // the shards this launch covers: blockIdx.y + shard_base (groups of shards run as
+    uint32_t shard_base, shard_count; // the shards this launch covers: shard_base .. + shard_count (groups of shards run as
                                       // independent wavefront loops on their own streams, see api.cpp)
     // queue policy, decided on the device from the shard's own counters (no host lag):
     float compact_below;     // re-pack a shard's queue when alive < compact_below * length (> 1: always, 0: never)
@@ -94,7 +95,7 @@ struct FrameParams {
     uint32_t width, height, spp, max_depth, rr_start, seed_hashed, sample_offset;
     float ray_eps;
     uint32_t rank, nranks, tiles_x, n_tiles;
-    uint32_t streams;          // K sample streams per pixel (docs/SPEC.md §5); slot = stream * slots_per_stream + pixel slot
+    uint32_t streams;          // K sample streams per pixel (docs/SPEC.md §5); slot <-> (pixel slot, stream): kernels.hip slot_of()
     uint32_t slots_per_stream; // pixel slots of this rank (tiles_per_rank * 4096)
     uint32_t accumulate;       // PT_FLAG_ACCUMULATE: keep the partial sums of the previous frame(s)
 };
