@@ -201,6 +201,9 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable_6290": round(achieved / HBM_ACHIEVABLE_GBS, 4),
             "traffic": traffic,
             "bytes_per_ray": round(b_ray, 1), "traversal_bytes_per_ray": round(b_trav, 1),
+            # SURVEY.md §8d writes the per-segment queue traffic of a two-kernel wavefront design (Q = 172 B) where this
+            # fused design moves 112 B per path state per launch; the same formula with Q = 172 for comparison:
+            "bytes_per_ray_survey_8d_q172": round(b_trav + 172.0 + 32.0 * sp.paths / sp.rays, 1),
             "path_states_per_ray": round(int(sp.reserved[2]) / sp.rays, 3), "nodes_per_ray": round(n_nodes_ray, 2), "tris_per_ray": round(n_tris_ray, 2),
             "spheres_per_ray": round(n_sph_ray, 2), "launches": launches, "mean_launch_ms": round(sp.extend_ms / launches, 4),
             "bytes_per_launch": round(b_ray * sp.rays / launches), "rays_per_launch": round(sp.rays / launches, 1),
