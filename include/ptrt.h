@@ -63,6 +63,8 @@ enum {
                                      loses its coalescing; kept for comparison (implies PT_FLAG_SPLIT_KERNELS) */
     PT_FLAG_SPLIT_KERNELS = 64u,  /* run extend and shade as two kernels per iteration (hit records through HBM) instead of shading
                                      inside the extend kernel; same frame, lets PT_FLAG_PROFILE_KERNELS time the two separately */
+    PT_FLAG_EXTEND_POOL = 128u,   /* force the pooled extend kernel (a wavefront owns 128 queue entries, refills idle lanes during
+                                     traversal and shades the whole pool at full width) */
     PT_FLAG_ACCUMULATE = 16u     /* progressive rendering: keep the sums of the previous call(s) (same size/rank/streams/seed,
                                      sample_offset = samples so far) and show the mean over all samples — the converging analogue
                                      of the reference's render-every-frame loop (App.cs:39-42) */

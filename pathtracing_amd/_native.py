@@ -35,6 +35,7 @@ PT_REFERENCE_SPHERE, PT_PATH_TRACE = 0, 1
 PT_LAMBERT, PT_METAL, PT_DIELECTRIC = 0, 1, 2
 PT_FLAG_PROFILE_KERNELS, PT_FLAG_COUNT_VISITS, PT_FLAG_EXTEND_PACKED, PT_FLAG_EXTEND_SIMPLE, PT_FLAG_ACCUMULATE, PT_FLAG_BUCKET_SPECULAR = 1, 2, 4, 8, 16, 32
 PT_FLAG_SPLIT_KERNELS = 64
+PT_FLAG_EXTEND_POOL = 128
 PT_SCENE_CORNELL, PT_SCENE_CORNELL_GLASS, PT_SCENE_TRIANGLE_SOUP, PT_SCENE_CORNELL_TESS = 0, 1, 2, 3
 PT_BVH_WIDTH_2, PT_BVH_WIDTH_4, PT_BVH_WIDTH_4Q, PT_BVH_WIDTH_8Q, PT_BVH_BUILD_LBVH = 2, 4, 68, 72, 0x100
 

@@ -449,7 +449,9 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     const uint32_t packed_chunk = chunk_env >= 64u ? chunk_env : ((p->streams >= 4u) ? 256u : 128u);
     const bool bucket_specular = (p->flags & PT_FLAG_BUCKET_SPECULAR) != 0;
     const bool split_kernels = bucket_specular || (p->flags & PT_FLAG_SPLIT_KERNELS) != 0;
-    const uint32_t forced_choice =(p->flags & PT_FLAG_EXTEND_PACKED) ? 2u : (p->flags & PT_FLAG_EXTEND_SIMPLE) ? 1u : 0u;
+    static const uint32_t kernel_env = [] { const char *e = getenv("PTRT_KERNEL"); return e ? (uint32_t)atoi(e) : 0u; }(); // tuning aid: 1, 2, 3
+    const uint32_t forced_choice = (p->flags & PT_FLAG_EXTEND_POOL) ? (uint32_t)EXT_POOL : (p->flags & PT_FLAG_EXTEND_PACKED) ? (uint32_t)EXT_PACKED
+                                   : (p->flags & PT_FLAG_EXTEND_SIMPLE) ? (uint32_t)EXT_SIMPLE : (kernel_env >= 1u && kernel_env <= 3u) ? kernel_env : 0u;
 
     if (p->mode == PT_REFERENCE_SPHERE) {
         // Renderer.ComputeFrame: one dispatch, then the host blocks on the fence (Renderer.cs:1020,1036,972)
@@ -479,7 +481,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     const uint32_t streams = p->streams ? p->streams : 1u;
     const uint32_t pixel_slots = lay.tiles_per_rank * kTilePixels;              // one slot per owned pixel ...
     const uint64_t slots64 = (uint64_t)pixel_slots * streams;                   // ... per sample stream
-    if (slots64 >= (1ull << 31)) return fail(c, PT_ERR_UNSUPPORTED, "frame too large");
+    if (slots64 >= (1ull << 28)) return fail(c, PT_ERR_UNSUPPORTED, "frame too large: %llu slots (pixels of this rank x streams), limit 2^28", (unsigned long long)slots64); // kernels.hip at(): 32-bit byte offsets
     const uint32_t n_slots = (uint32_t)slots64;
 
     HIP_TRY(c, c->ray_o.ensure(n_slots)); HIP_TRY(c, c->ray_d.ensure(n_slots)); HIP_TRY(c, c->thr.ensure(n_slots));
@@ -531,7 +533,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     // one loop. Inside a loop a shard's queue can only shrink (slots die, none are born), so the queue sizes read back
     // kLag iterations ago are valid launch bounds: the host never stalls the GPU to size a grid.
     // per-kernel timing, visit counting and the extend-kernel probe (events around single iterations) want kernels alone on the GPU
-    const bool will_probe = !(p->flags & (PT_FLAG_EXTEND_PACKED | PT_FLAG_EXTEND_SIMPLE)) && s->ext_choice == 0u;
+    const bool will_probe = forced_choice == 0u && s->ext_choice == 0u;
     const uint32_t n_loops = (profile || count || will_probe) ? 1u : c->groups ? c->groups : (n_slots <= kTwoLoopsBelow ? 2u : 1u);
     const uint32_t per_group = kShards / n_loops;
     //
@@ -575,14 +577,15 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
                 HIP_TRY(c, hipEventRecord(e0, L.stream));
             }
             const bool probing = g == 0u && ext_choice == 0u && (L.iters == 2u || L.iters == 3u);
-            const bool use_packed = ext_choice == 2u || (probing && L.iters == 3u);
+            const bool use_packed = ext_choice == (uint32_t)EXT_PACKED || (probing && L.iters == 3u);
+            const int kernel = use_packed ? EXT_PACKED : (ext_choice == (uint32_t)EXT_POOL && !split_kernels) ? EXT_POOL : EXT_SIMPLE;
             const bool compact = bucket_specular; // forced: buckets re-append, there are no fixed positions
             // One kernel per iteration by default: the one-ray-per-lane k_extend shades its own hits (mode 0: Lambert-only
             // scene, lean code; 2: all kinds). The lane-packing kernel and the bucketed pipeline keep k_shade as a second kernel.
             const int shade_mode = s->has_specular ? 2 : 0;
             const bool fused = !split_kernels;
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
-            HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, use_packed ? packed_chunk : 0u, fused ? shade_mode : -1, compact,
+            HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, kernel, packed_chunk, fused ? shade_mode : -1, compact,
                                      c->bounces ? c->bounces : use_packed ? 8u : std::min(8u, std::max(4u, p->max_depth / 2u)))); // lane-packing: a lane
                                      // pulls a new entry whenever its budget ends, so a long budget costs nothing (soup: 3.13 -> 3.23 Grays/s)
             if (profile) HIP_TRY(c, hipEventRecord(e1, L.stream));

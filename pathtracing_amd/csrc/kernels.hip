@@ -46,6 +46,28 @@ PT_DEV void wave_push(uint32_t *counter, uint32_t *queue, bool pred, uint32_t va
     if (pred) queue[base + prefix] = value;
 }
 
+// Kernel arguments of the extend kernels: ONE by-value block (the kernarg segment). Hot fields (node / triangle / stack
+// pointers, counts) are read from the parameter as usual; everything only the shading / regeneration / queueing code wants
+// (camera, sky, frame parameters, path-state pointers) is read through cold(): the kernel's own kernarg segment behind an
+// opaque copy of its address, so that those scalar loads are issued where they are used instead of being hoisted to the
+// kernel entry and kept live in SGPRs across the traversal loop (which is what spilled 57 SGPRs to VGPR lanes and 20 B/lane
+// of scratch in round 1).
+struct ExtArgs {
+    DeviceScene sc; PathState ps; FrameParams fp;
+    uint32_t it, compact, bounces, chunk;
+};
+// Element `i` of a slot-indexed array by a 32-bit byte offset (api.cpp keeps n_slots * 16 below 2^32): the address is an SGPR
+// base plus one VGPR offset, instead of a 64-bit address in a VGPR pair per array that stays live across the traversal loop.
+template <typename T>
+PT_DEV T &at(T *base, uint32_t i) { return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (size_t)(i * (uint32_t)sizeof(T))); }
+
+PT_DEV const ExtArgs &cold()
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr(); // constant address space: scalar loads
+    asm volatile("" : "+s"(p));
+    return *(const ExtArgs *)p;
+}
+
 // Slot order. A slot is one (pixel slot, stream) pair; 64 consecutive slots are one 8x8 pixel block of one stream (a
 // wavefront). PT_STREAM_INNER: the K streams of a block are K consecutive 64-slot groups, so that wavefronts that run
 // at the same time work on the same few tiles of the image (their primary rays want the same corner of the scene,
@@ -168,8 +190,8 @@ template <int L>
 PT_DEV constexpr int fanout() { return L == PT_BVH_WIDTH_2 ? 2 : L == PT_BVH_WIDTH_8Q ? 8 : 4; }
 
 template <int L>
-PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, float4 r2, float4 r3, const RaySetup &rs, float t_best,
-                       uint32_t (&key)[fanout<L>()], int32_t (&ref)[fanout<L>()])
+PT_DEV void visit_node_keys(const float4 *__restrict__ nd, float4 r0, float4 r1, float4 r2, float4 r3, const RaySetup &rs, float t_best,
+                            uint32_t (&key)[fanout<L>()], int32_t (&ref)[fanout<L>()])
 {
     constexpr int N = fanout<L>();
     if constexpr (L == PT_BVH_WIDTH_8Q) {
@@ -255,19 +277,41 @@ PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, floa
             key[c] = hb ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
         }
     }
-    auto cswap = [&](int a, int b) {
-        if (key[a] > key[b]) {
-            const uint32_t tk = key[a]; key[a] = key[b]; key[b] = tk;
-            const int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
-        }
-    };
-    if constexpr (N == 2) { cswap(0, 1); }
-    else if constexpr (N == 4) { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); }
-    else { // 19-comparator network for 8 keys
-        cswap(0, 1); cswap(2, 3); cswap(4, 5); cswap(6, 7); cswap(0, 2); cswap(1, 3); cswap(4, 6); cswap(5, 7);
-        cswap(1, 2); cswap(5, 6); cswap(0, 4); cswap(3, 7); cswap(1, 5); cswap(2, 6); cswap(1, 4); cswap(3, 6);
-        cswap(2, 4); cswap(3, 5); cswap(3, 4);
+}
+
+// Sorting network over (key, ref), ascending key, in two halves: after sort_head the nearest hit child is in slot 0 (so its
+// fetch can be issued), sort_tail finishes the order of the others (which only the pushes need).
+template <int N>
+PT_DEV void cswap(uint32_t (&key)[N], int32_t (&ref)[N], int a, int b)
+{
+    if (key[a] > key[b]) {
+        const uint32_t tk = key[a]; key[a] = key[b]; key[b] = tk;
+        const int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
     }
+}
+template <int N>
+PT_DEV void sort_head(uint32_t (&key)[N], int32_t (&ref)[N])
+{
+    if constexpr (N == 2) { cswap(key, ref, 0, 1); }
+    else if constexpr (N == 4) { cswap(key, ref, 0, 1); cswap(key, ref, 2, 3); cswap(key, ref, 0, 2); }
+    else { // 19-comparator network for 8 keys, whole
+        cswap(key, ref, 0, 1); cswap(key, ref, 2, 3); cswap(key, ref, 4, 5); cswap(key, ref, 6, 7); cswap(key, ref, 0, 2); cswap(key, ref, 1, 3);
+        cswap(key, ref, 4, 6); cswap(key, ref, 5, 7); cswap(key, ref, 1, 2); cswap(key, ref, 5, 6); cswap(key, ref, 0, 4); cswap(key, ref, 3, 7);
+        cswap(key, ref, 1, 5); cswap(key, ref, 2, 6); cswap(key, ref, 1, 4); cswap(key, ref, 3, 6); cswap(key, ref, 2, 4); cswap(key, ref, 3, 5);
+        cswap(key, ref, 3, 4);
+    }
+}
+template <int N>
+PT_DEV void sort_tail(uint32_t (&key)[N], int32_t (&ref)[N])
+{
+    if constexpr (N == 4) { cswap(key, ref, 1, 3); cswap(key, ref, 1, 2); }
+}
+template <int L>
+PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, float4 r2, float4 r3, const RaySetup &rs, float t_best,
+                       uint32_t (&key)[fanout<L>()], int32_t (&ref)[fanout<L>()])
+{
+    visit_node_keys<L>(nd, r0, r1, r2, r3, rs, t_best, key, ref);
+    sort_head(key, ref); sort_tail(key, ref);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -285,17 +329,17 @@ struct PathRegs {
 };
 PT_DEV void path_load(const PathState &ps, uint32_t slot, PathRegs &r)
 {
-    const float4 O = ps.ray_o[slot], D = ps.ray_d[slot], TK = ps.thr[slot];
-    const uint32_t sdv = ps.sd[slot];
+    const float4 O = at(ps.ray_o, slot), D = at(ps.ray_d, slot), TK = at(ps.thr, slot);
+    const uint32_t sdv = at(ps.sd, slot);
     r.o = xyz(O); r.d = xyz(D); r.T = xyz(TK);
     r.key = __float_as_uint(TK.w); r.sample = sdv >> 8; r.depth = sdv & 255u;
 }
 PT_DEV void path_store(const PathState &ps, uint32_t slot, const PathRegs &r)
 {
-    ps.ray_o[slot] = make_float4(r.o.x, r.o.y, r.o.z, 0.f);
-    ps.ray_d[slot] = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
-    ps.thr[slot] = make_float4(r.T.x, r.T.y, r.T.z, __uint_as_float(r.key));
-    ps.sd[slot] = (r.sample << 8) | r.depth;
+    at(ps.ray_o, slot) = make_float4(r.o.x, r.o.y, r.o.z, 0.f);
+    at(ps.ray_d, slot) = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
+    at(ps.thr, slot) = make_float4(r.T.x, r.T.y, r.T.z, __uint_as_float(r.key));
+    at(ps.sd, slot) = (r.sample << 8) | r.depth;
 }
 
 template <int MODE>
@@ -308,7 +352,7 @@ PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FramePar
     float4 A = make_float4(0.f, 0.f, 0.f, 0.f); // the slot's radiance sum | path count: read on first use, written back below
     bool touched = false, term = false, alive = false;
     auto add = [&](V3 L) {
-        if (!touched) { A = ps.acc[slot]; touched = true; }
+        if (!touched) { A = at(ps.acc, slot); touched = true; }
         A.x = fma_(T.x, L.x, A.x); A.y = fma_(T.y, L.y, A.y); A.z = fma_(T.z, L.z, A.z);
     };
 
@@ -341,14 +385,14 @@ PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FramePar
         if (depth >= fp.max_depth) term = true;
         else {
             const uint32_t bb = depth - 1u;
-            V3 wi = d, W = v3(1.f, 1.f, 1.f);
-            float side = 1.0f;
-            bool ok = true;
             const uint32_t bk = MODE == SHADE_QUEUE ? (uint32_t)B_LAMBERT : MODE == SHADE_BUCKETS ? b : 1u + kind;
-            if (bk == B_LAMBERT) sample_lambert(alb, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
-            else if (bk == B_METAL) ok = sample_metal(alb, m1.w, d, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb), wi, W);
-            else sample_dielectric(alb, m2.x, d, n, front, u01(key, 6u + 4u * bb), wi, W, side);
-            if (!ok) term = true;
+            BsdfSample bs;
+            if (bk == B_LAMBERT) bs = sample_lambert(alb, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb));
+            else if (bk == B_METAL) bs = sample_metal(alb, m1.w, d, n, u01(key, 4u + 4u * bb), u01(key, 5u + 4u * bb));
+            else bs = sample_dielectric(alb, m2.x, d, n, front, u01(key, 6u + 4u * bb));
+            const V3 wi = bs.wi, W = bs.W;
+            const float side = bs.side;
+            if (!bs.ok) term = true;
             else {
                 T = v3(T.x * W.x, T.y * W.y, T.z * W.z);
                 if (!(fmax_(T.x, fmax_(T.y, T.z)) > 0.0f)) term = true;
@@ -363,7 +407,7 @@ PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FramePar
     }
 
     if (term) {
-        if (!touched) { A = ps.acc[slot]; touched = true; }
+        if (!touched) { A = at(ps.acc, slot); touched = true; }
         A.w += 1.0f;
         sample += fp.streams;
         if (sample < fp.spp) { // regenerate this stream's next sample of the pixel in place
@@ -376,7 +420,7 @@ PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FramePar
             alive = true;
         }
     } else alive = true;
-    if (touched) ps.acc[slot] = A;
+    if (touched) at(ps.acc, slot) = A;
     r.depth = depth;
     return alive;
 }
@@ -427,57 +471,142 @@ PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint
 // Occupancy is worth more to this kernel than a few spills: it hides the latency of divergent node gathers with waves, and
 // unconstrained the fused variants take 84-89 VGPRs (5 waves/SIMD). Measured on the 1M-triangle Cornell box (Mrays/s):
 // 5 waves 9555, 6 waves 10326, 7 waves 10849 (SGPR spills only); the all-kinds variant spills 9 VGPRs at 7 and prefers 6.
-#ifndef PT_WHILE_WHILE
-#define PT_WHILE_WHILE 1
-#endif
 #ifndef PT_EXT_WAVES
 #define PT_EXT_WAVES(FUSE) ((FUSE) == SHADE_INLINE ? 6 : 7)
 #endif
-template <int L, bool COUNT, int FUSE>
-__global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(PT_EXT_WAVES(FUSE), PT_EXT_WAVES(FUSE)))) k_extend(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint32_t compact, uint32_t bounces)
+// A lane's traversal stack: kStackLds entries in its LDS column ([level][lane]: conflict-free), the rest in a global
+// overflow column sized by the builder's exact worst case (pt_bvh_info.stack_need).
+struct StackCtx { int32_t *lds; uint32_t stride, tid, col; }; // col: the lane's column of the overflow area, unique per thread of a launch
+PT_DEV void push_slow(const StackCtx &k, uint32_t &sp, int32_t v)
 {
-    const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u, czero = (it + 2u) % 3u;
+    if (sp < kStackLds) k.lds[sp * k.stride + k.tid] = v;
+    else {
+        const PathState &ps = cold().ps;
+        const uint32_t e = sp - kStackLds;
+        if (e < ps.stack_ovf_entries) ps.stack_ovf[(size_t)e * ((size_t)kShards * ps.shard_cap) + k.col] = v;
+        else { atomicOr(&ps.counters[kCntError], 1u); return; }
+    }
+    ++sp;
+}
+PT_DEV int32_t pop_slow(const StackCtx &k, uint32_t &sp)
+{
+    if (sp == 0) return PT_BVH_EMPTY;
+    --sp;
+    if (sp < kStackLds) return k.lds[sp * k.stride + k.tid];
+    const PathState &ps = cold().ps;
+    return ps.stack_ovf[(size_t)(sp - kStackLds) * ((size_t)kShards * ps.shard_cap) + k.col];
+}
+
+// One inner-node visit of the lanes that call it: fetch, slab tests, children pushed farthest first, nearest (or the popped
+// stack top) becomes `cur`. Stack fast path: while every calling lane still has room for a whole node's pushes in its LDS column
+// (the common case), a push is an unconditional LDS store plus a predicated increment and a pop is a plain LDS load — no
+// LDS-or-spill branch per push.
+template <int L>
+PT_DEV void node_step(const float4 *__restrict__ nodes, const StackCtx &k, const RaySetup &rs, float t_best, int32_t &cur, uint32_t &sp)
+{
     constexpr int N = fanout<L>();
+    const float4 *base = nodes + (size_t)cur * node_rows<L>();
+    const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
+    const bool deep = __any((int)(sp + (uint32_t)(N - 1) > kStackLds)) != 0;
+    uint32_t key[N];
+    int32_t ref[N];
+    visit_node<L>(base, r0, r1, r2, r3, rs, t_best, key, ref); // keys sorted ascending, misses = 0xFFFFFFFF at the end
+    if (!deep) {
+#pragma unroll
+        for (int i = N - 1; i >= 1; --i) { // farthest first, nearest stays in `cur`
+            k.lds[sp * k.stride + k.tid] = ref[i];
+            sp += key[i] != 0xFFFFFFFFu ? 1u : 0u;
+        }
+        if (key[0] != 0xFFFFFFFFu) cur = ref[0];
+        else if (sp) { --sp; cur = k.lds[sp * k.stride + k.tid]; }
+        else cur = PT_BVH_EMPTY;
+    } else {
+#pragma unroll
+        for (int i = N - 1; i >= 1; --i)
+            if (key[i] != 0xFFFFFFFFu) push_slow(k, sp, ref[i]);
+        cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop_slow(k, sp);
+    }
+}
+
+// One leaf of the lanes that call it: its triangles in array order, then the next stack entry. Returns the triangle tests made.
+PT_DEV uint32_t leaf_step(const float4 *__restrict__ tris, const StackCtx &k, V3 o, V3 d, Hit &h, int32_t &cur, uint32_t &sp)
+{
+    const uint32_t enc = (uint32_t)~cur;
+    uint32_t first = enc >> 3, more = enc & 7u, n = 0;
+    for (;;) {
+        const float4 *base = tris + (size_t)first * 4;
+        const float4 r0 = base[0], r1 = base[1], r2 = base[2];
+        tri_test(r0, r1, r2, first, o, d, h);
+        ++n;
+        if (more == 0u) break;
+        ++first; --more;
+    }
+    const bool deep = __any((int)(sp > kStackLds)) != 0;
+    if (!deep) { if (sp) { --sp; cur = k.lds[sp * k.stride + k.tid]; } else cur = PT_BVH_EMPTY; }
+    else cur = pop_slow(k, sp);
+    return n;
+}
+
+// Finish mode (n_alive <= finish_below): a launch keeps going until its paths end, but never for more than this many
+// vertices per lane, so that a launch stays bounded whatever spp and max_depth are; the host loop simply goes on.
+constexpr uint32_t kFinishVertices = 256;
+
+template <int L, bool COUNT, int FUSE>
+__global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(PT_EXT_WAVES(FUSE), PT_EXT_WAVES(FUSE)))) k_extend(ExtArgs a)
+{
+    // hot arguments (stay in SGPRs across the traversal loop); everything else goes through cold()
+    const float4 *__restrict__ nodes = a.sc.nodes, *__restrict__ tris = a.sc.tris, *__restrict__ spheres = a.sc.spheres;
+    const uint32_t n_spheres = a.sc.n_spheres, n_tris = a.sc.n_tris, n_nodes = a.sc.n_nodes;
+    const uint32_t it = a.it;
+    const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u, czero = (it + 2u) % 3u;
     __shared__ int32_t s_stack[kStackLds * kExtBlock];
     __shared__ uint32_t s_stash[(FUSE != SHADE_NONE ? 5 : 1) * kExtBlock];
-    volatile uint32_t *stash = s_stash; // volatile: the values must really leave the registers
+    uint32_t *stash = s_stash;
     uint32_t shard, bx, nbx;
-    block_pos(ps, shard, bx, nbx);
-    const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)], n_alive = ps.counters[cnt_alive_index(ccur, shard)];
+    block_pos(a.ps, shard, bx, nbx);
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = bx * kExtBlock + tid;                  // index inside the shard's queue
-    const bool do_compact = FUSE != SHADE_NONE && want_compact(ps, n, n_alive, compact != 0u);
-    if (gid == 0) {
-        ps.counters[cnt_ext_index(czero, shard)] = 0u;         // the queue after next
-        ps.counters[cnt_alive_index(czero, shard)] = 0u;
-        fold_traced(ps, shard, it);
-        if (FUSE == SHADE_NONE) *traced_counter(ps, cnext, shard) = n_alive; // one ray per alive entry; the fused kernel
-                                                                             // counts what it traces, per wavefront
-        if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
+    uint32_t n, n_alive, slot = kInvalidSlot, n_bounces;
+    bool do_compact;
+    size_t qbase;
+    {
+        const PathState &ps = cold().ps;
+        n = ps.counters[cnt_ext_index(ccur, shard)]; n_alive = ps.counters[cnt_alive_index(ccur, shard)];
+        do_compact = FUSE != SHADE_NONE && want_compact(ps, n, n_alive, a.compact != 0u);
+        if (gid == 0) {
+            ps.counters[cnt_ext_index(czero, shard)] = 0u;         // the queue after next
+            ps.counters[cnt_alive_index(czero, shard)] = 0u;
+            fold_traced(ps, shard, it);
+            if (FUSE == SHADE_NONE) *traced_counter(ps, cnext, shard) = n_alive; // one ray per alive entry; the fused kernel
+                                                                                 // counts what it traces, per wavefront
+            if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
+        }
+        if (bx * kExtBlock >= n || n_alive == 0u) return;
+        qbase = (size_t)shard * ps.shard_cap;
+        if (gid < n) slot = ps.q_ext[parity][qbase + gid];
+        // FUSE: up to `bounces` path vertices per launch with the path state in registers (a terminated path continues with
+        // its stream's next camera ray, so most lanes stay busy); the state goes back to memory once, at the end.
+        // Once few paths are left in the shard (the frame's tail) the launch runs them to their end instead (bounded by
+        // kFinishVertices): launches that small cost more in launch latency and host round trips than the lanes idling
+        // behind a wave's longest path. A launch that STARTS sparse (many paths ended during the previous one) runs every
+        // wavefront at the cost of its few live lanes; it advances one vertex only, re-packs, and the dense launch after
+        // it does the real work.
+        const bool sparse = do_compact && (float)n_alive < ps.sparse_below * (float)n;
+        n_bounces = FUSE == SHADE_NONE ? 1u : (n_alive <= ps.finish_below ? kFinishVertices : sparse ? 1u : a.bounces);
     }
-    if (bx * kExtBlock >= n || n_alive == 0u) return;
-    const size_t qbase = (size_t)shard * ps.shard_cap;
-    const uint32_t slot = gid < n ? ps.q_ext[parity][qbase + gid] : kInvalidSlot;
     const bool active = slot != kInvalidSlot;                  // holes: paths that ended since the queue was last compacted
-    const size_t uid = qbase + gid;                            // unique per thread of this launch
+    const StackCtx stk{ s_stack, kExtBlock, tid, (uint32_t)qbase + gid };
 
     unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0, c_wave_iters = 0, c_wave_iters_late = 0;
     PathRegs r;
     r.o = v3(0.f, 0.f, 0.f); r.d = v3(0.f, 0.f, 1.f); r.T = v3(0.f, 0.f, 0.f); r.key = r.sample = r.depth = 0u;
     if (active) {
-        if (FUSE == SHADE_NONE) { r.o = xyz(ps.ray_o[slot]); r.d = xyz(ps.ray_d[slot]); }
+        const PathState &ps = cold().ps;
+        if (FUSE == SHADE_NONE) { r.o = xyz(at(ps.ray_o, slot)); r.d = xyz(at(ps.ray_d, slot)); }
         else path_load(ps, slot, r);
     }
     bool alive = active;
     uint32_t wave_rays = 0;
-    // FUSE: up to `bounces` path vertices per launch with the path state in registers (a terminated path continues with
-    // its stream's next camera ray, so most lanes stay busy); the state goes back to memory once, at the end.
-    // Once few paths are left in the shard (the frame's tail) the launch runs them to their end instead: launches that
-    // small cost more in launch latency and host round trips than the lanes idling behind a wave's longest path.
-    // A launch that STARTS sparse (many paths ended during the previous one) runs every wavefront at the cost of its few
-    // live lanes; it advances one vertex only, re-packs, and the dense launch after it does the real work.
-    const bool sparse = do_compact && (float)n_alive < ps.sparse_below * (float)n;
-    const uint32_t n_bounces = FUSE == SHADE_NONE ? 1u : (n_alive <= ps.finish_below ? 0xFFFFFFFFu : sparse ? 1u : bounces);
     for (uint32_t bounce = 0; bounce < n_bounces; ++bounce) {
     const uint64_t alive_mask = __ballot(alive);
     if (alive_mask == 0) break;
@@ -489,34 +618,18 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
             stash[0 * kExtBlock + tid] = __float_as_uint(r.T.x); stash[1 * kExtBlock + tid] = __float_as_uint(r.T.y);
             stash[2 * kExtBlock + tid] = __float_as_uint(r.T.z); stash[3 * kExtBlock + tid] = r.key;
             stash[4 * kExtBlock + tid] = (r.sample << 8) | r.depth;
+            asm volatile("" ::: "memory"); // the values must really leave the registers: no store-to-load forwarding across the traversal
         }
 
-        for (uint32_t j = 0; j < sc.n_spheres; ++j) { // uniform index => scalar loads
-            sphere_test(sc.spheres[j], sc.n_tris + j, o, d, h);
+        for (uint32_t j = 0; j < n_spheres; ++j) { // uniform index => scalar loads
+            sphere_test(spheres[j], n_tris + j, o, d, h);
             if (COUNT) c_sph++;
         }
 
         const RaySetup rs = ray_setup(o, d);
-        int32_t cur = sc.n_nodes ? 0 : PT_BVH_EMPTY;
+        int32_t cur = n_nodes ? 0 : PT_BVH_EMPTY;
         uint32_t sp = 0, steps = 0;
-        const size_t ovf_stride = (size_t)kShards * ps.shard_cap;
 
-        auto push = [&](int32_t v) {
-            if (sp < kStackLds) s_stack[sp * kExtBlock + tid] = v;
-            else {
-                const uint32_t e = sp - kStackLds;
-                if (e < ps.stack_ovf_entries) ps.stack_ovf[(size_t)e * ovf_stride + uid] = v;
-                else { atomicOr(&ps.counters[kCntError], 1u); return; }
-            }
-            ++sp;
-        };
-        auto pop = [&]() -> int32_t {
-            if (sp == 0) return PT_BVH_EMPTY;
-            --sp;
-            return sp < kStackLds ? s_stack[sp * kExtBlock + tid] : ps.stack_ovf[(size_t)(sp - kStackLds) * ovf_stride + uid];
-        };
-
-#if PT_WHILE_WHILE
         // while-while: a lane that reaches a leaf waits at the reconvergence point of the node loop until every lane of
         // the wave is at a leaf or done; then the leaves are tested together. Each lane still makes exactly the visits,
         // in exactly the order, of docs/SPEC.md §4.1 (only the interleaving across lanes changes), so hits and visit
@@ -526,107 +639,32 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
         bool late_cycle = false; // (COUNT diagnostics) set once this wave has run a leaf phase for the current rays
         for (;;) {
             while ((uint32_t)cur < (uint32_t)PT_BVH_EMPTY) { // ---- node phase: inner-node refs are 0 .. 0x7ffffffe (EMPTY = 0x7fffffff)
-                if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; break; }
-                const float4 *base = sc.nodes + (size_t)cur * node_rows<L>();
-                const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
-                const bool deep = __any((int)(sp + (uint32_t)(N - 1) > kStackLds)) != 0; // stack fast path, see below
-                uint32_t key[N];
-                int32_t ref[N];
-                visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref); // keys sorted ascending, misses = 0xFFFFFFFF at the end
+                if (++steps > (1u << 22)) { atomicOr(&cold().ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; break; }
                 if (COUNT) { // one lane per wave-iteration counts it; [1]: iterations after the wave's first leaf phase of this ray
                     c_nodes++;
                     if (lane_id() == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) { c_wave_iters++; if (late_cycle) c_wave_iters_late++; }
                 }
-                if (!deep) {
-#pragma unroll
-                    for (int i = N - 1; i >= 1; --i) { // farthest first, nearest stays in `cur`
-                        s_stack[sp * kExtBlock + tid] = ref[i];
-                        sp += key[i] != 0xFFFFFFFFu ? 1u : 0u;
-                    }
-                    if (key[0] != 0xFFFFFFFFu) cur = ref[0];
-                    else if (sp) { --sp; cur = s_stack[sp * kExtBlock + tid]; }
-                    else cur = PT_BVH_EMPTY;
-                } else {
-#pragma unroll
-                    for (int i = N - 1; i >= 1; --i)
-                        if (key[i] != 0xFFFFFFFFu) push(ref[i]);
-                    cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop();
-                }
+                node_step<L>(nodes, stk, rs, h.t, cur, sp);
             }
             if (cur == PT_BVH_EMPTY) break;
-            { // ---- leaf phase: its triangles in array order
-                if (COUNT) late_cycle = true;
-                const uint32_t enc = (uint32_t)~cur;
-                uint32_t first = enc >> 3, more = enc & 7u;
-                for (;;) {
-                    const float4 *base = sc.tris + (size_t)first * 4;
-                    const float4 r0 = base[0], r1 = base[1], r2 = base[2];
-                    tri_test(r0, r1, r2, first, o, d, h);
-                    if (COUNT) c_tris++;
-                    if (more == 0u) break;
-                    ++first; --more;
-                }
-                const bool deep = __any((int)(sp > kStackLds)) != 0;
-                if (!deep) { if (sp) { --sp; cur = s_stack[sp * kExtBlock + tid]; } else cur = PT_BVH_EMPTY; }
-                else cur = pop();
-            }
+            if (COUNT) late_cycle = true;
+            const uint32_t nt = leaf_step(tris, stk, o, d, h, cur, sp); // ---- leaf phase
+            if (COUNT) c_tris += nt;
         }
-#else
-        while (cur != PT_BVH_EMPTY) {
-            if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); break; }
-            // one fetch for both kinds of step: 4 rows from the node, or from the first triangle of the leaf
-            const bool inner = cur >= 0;
-            const uint32_t enc = (uint32_t)~cur, first = enc >> 3, more = enc & 7u; // leaf: `more` triangles after this one
-            const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 4;
-            const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
-            // Stack fast path. While every lane of the wave still has room for a whole node's pushes in its LDS column (the
-            // common case), a push is an unconditional LDS store plus a predicated increment and a pop is a plain LDS load —
-            // no LDS-or-spill branch per push. (The branching version was 76 of the ~340 instructions of a loop iteration,
-            // and the kernel is VALU-issue bound.) The spilling code runs only when some lane is near the end of its column.
-            const bool deep = __any((int)(sp + (uint32_t)(N - 1) > kStackLds)) != 0;
-            auto pop_fast = [&]() -> int32_t {
-                if (sp == 0) return PT_BVH_EMPTY;
-                --sp;
-                return s_stack[sp * kExtBlock + tid];
-            };
-            if (inner) {
-                uint32_t key[N];
-                int32_t ref[N];
-                visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref); // keys sorted ascending, misses = 0xFFFFFFFF at the end
-                if (COUNT) c_nodes++;
-                if (!deep) {
-#pragma unroll
-                    for (int i = N - 1; i >= 1; --i) { // farthest first, nearest stays in `cur`
-                        s_stack[sp * kExtBlock + tid] = ref[i];
-                        sp += key[i] != 0xFFFFFFFFu ? 1u : 0u;
-                    }
-                    cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop_fast();
-                } else {
-#pragma unroll
-                    for (int i = N - 1; i >= 1; --i)
-                        if (key[i] != 0xFFFFFFFFu) push(ref[i]);
-                    cur = (key[0] != 0xFFFFFFFFu) ? ref[0] : pop();
-                }
-            } else {
-                tri_test(r0, r1, r2, first, o, d, h);
-                if (COUNT) c_tris++;
-                // rest of the leaf, in array order
-                cur = more ? (int32_t)~(((first + 1u) << 3) | (more - 1u)) : (deep ? pop() : pop_fast());
-            }
-        }
-#endif
 
-        if (FUSE == SHADE_NONE) ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref)); // k_shade walks the same queue in the same order
+        if (FUSE == SHADE_NONE) at(cold().ps.hit, slot) = make_float2(h.t, __uint_as_float(h.ref)); // k_shade walks the same queue in the same order
         else {
             r.T = v3(__uint_as_float(stash[0 * kExtBlock + tid]), __uint_as_float(stash[1 * kExtBlock + tid]), __uint_as_float(stash[2 * kExtBlock + tid]));
             r.key = stash[3 * kExtBlock + tid];
             const uint32_t sdv = stash[4 * kExtBlock + tid];
             r.sample = sdv >> 8; r.depth = sdv & 255u;
             uint32_t defer = 0u;
-            alive = shade_one<FUSE>(sc, ps, fp, slot, r, h.t, h.ref, B_LAMBERT, defer);
+            const ExtArgs &c = cold();
+            alive = shade_one<FUSE>(c.sc, c.ps, c.fp, slot, r, h.t, h.ref, B_LAMBERT, defer);
         }
     }
     }
+    const PathState &ps = cold().ps;
     if (COUNT && active) {
         if (c_wave_iters) atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntWaveNodeIters), c_wave_iters);
         if (c_wave_iters_late) atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntWaveNodeIters + 2), c_wave_iters_late);
@@ -640,6 +678,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
         if (wave_rays && lane_id() == 0u) atomicAdd(traced_counter(ps, cnext, shard), (unsigned long long)wave_rays);
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // k_extend_packed: same per-ray work and the same per-ray traversal order as k_extend (so hits AND visit counters
@@ -658,39 +697,43 @@ constexpr uint32_t kRefillIdle = PT_REFILL_IDLE;
 // `bounces` vertices lasts, starts the path's next ray itself; only then does it hand the slot to the next iteration
 // and pull a new queue entry. Path state stays in registers / LDS across those bounces, and no bounce waits for the wave.
 #ifndef PT_PACKED_WAVES
-#define PT_PACKED_WAVES(FUSE) ((FUSE) == SHADE_NONE ? 7 : 6)
+#define PT_PACKED_WAVES(FUSE) ((FUSE) == SHADE_INLINE ? 6 : 7)
 #endif
 template <int L, bool COUNT, int FUSE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_PACKED_WAVES(FUSE), PT_PACKED_WAVES(FUSE))))
-k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint32_t chunk, uint32_t compact, uint32_t bounces)
+k_extend_packed(ExtArgs a)
 {
+    // hot arguments stay in SGPRs; everything else is read through cold() where it is used (see ExtArgs)
+    const float4 *__restrict__ nodes = a.sc.nodes, *__restrict__ tris = a.sc.tris, *__restrict__ spheres = a.sc.spheres;
+    const uint32_t n_spheres = a.sc.n_spheres, n_tris = a.sc.n_tris, n_nodes = a.sc.n_nodes;
+    const uint32_t it = a.it, chunk = a.chunk, compact = a.compact, bounces = a.bounces;
     constexpr int N = fanout<L>();
     __shared__ int32_t s_stack[kStackLds * 64];
     __shared__ uint32_t s_stash[(FUSE != SHADE_NONE ? 5 : 1) * 64];
-    volatile uint32_t *stash = s_stash;
+    uint32_t *stash = s_stash;
     const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u, czero = (it + 2u) % 3u;
     uint32_t shard, bx, nbx;
-    block_pos(ps, shard, bx, nbx);
-    const uint32_t n = ps.counters[cnt_ext_index(ccur, shard)], n_alive = ps.counters[cnt_alive_index(ccur, shard)];
+    block_pos(a.ps, shard, bx, nbx);
+    const uint32_t n = cold().ps.counters[cnt_ext_index(ccur, shard)], n_alive = cold().ps.counters[cnt_alive_index(ccur, shard)];
     const uint32_t lane = threadIdx.x;
-    const bool do_compact = FUSE != SHADE_NONE && want_compact(ps, n, n_alive, compact != 0u);
+    const bool do_compact = FUSE != SHADE_NONE && want_compact(cold().ps, n, n_alive, compact != 0u);
     if (bx == 0 && lane == 0) {
-        ps.counters[cnt_ext_index(czero, shard)] = 0u;
-        ps.counters[cnt_alive_index(czero, shard)] = 0u;
-        fold_traced(ps, shard, it);
-        if (FUSE == SHADE_NONE) *traced_counter(ps, cnext, shard) = n_alive; // one ray per alive entry
-        else if (!do_compact) ps.counters[cnt_ext_index(cnext, shard)] = n;  // carried in place: the length stays
-        if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
+        cold().ps.counters[cnt_ext_index(czero, shard)] = 0u;
+        cold().ps.counters[cnt_alive_index(czero, shard)] = 0u;
+        fold_traced(cold().ps, shard, it);
+        if (FUSE == SHADE_NONE) *traced_counter(cold().ps, cnext, shard) = n_alive; // one ray per alive entry
+        else if (!do_compact) cold().ps.counters[cnt_ext_index(cnext, shard)] = n;  // carried in place: the length stays
+        if (do_compact && n_alive) atomicAdd(&cold().ps.counters[kCntCompactions], 1u);
     }
     uint32_t next = bx * chunk;                               // wave-uniform cursor into the shard's queue
     if (next >= n || n_alive == 0u) return;
     const uint32_t end = min(n, next + chunk);
-    const size_t qbase = (size_t)shard * ps.shard_cap;
-    const uint32_t *queue = ps.q_ext[parity] + qbase;
-    uint32_t *q_next = ps.q_ext[parity ^ 1u] + qbase;
+    const size_t qbase = (size_t)shard * cold().ps.shard_cap;
+    const uint32_t *queue = cold().ps.q_ext[parity] + qbase;
+    uint32_t *q_next = cold().ps.q_ext[parity ^ 1u] + qbase;
     const size_t uid = qbase + (size_t)bx * 64u + lane;        // unique per thread of this launch (chunk >= 64)
-    const size_t ovf_stride = (size_t)kShards * ps.shard_cap;
-    const uint32_t budget0 = FUSE == SHADE_NONE ? 1u : (n_alive <= ps.finish_below ? 0xFFFFFFFFu : bounces);
+    const size_t ovf_stride = (size_t)kShards * cold().ps.shard_cap;
+    const uint32_t budget0 = FUSE == SHADE_NONE ? 1u : (n_alive <= cold().ps.finish_below ? kFinishVertices : bounces);
 
     bool has = false;                                          // lane holds a ray
     uint32_t slot = 0, pos = 0, budget = 0, sp = 0, steps = 0;
@@ -707,15 +750,15 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
         if (sp < kStackLds) s_stack[sp * 64u + lane] = v;
         else {
             const uint32_t e = sp - kStackLds;
-            if (e < ps.stack_ovf_entries) ps.stack_ovf[(size_t)e * ovf_stride + uid] = v;
-            else { atomicOr(&ps.counters[kCntError], 1u); return; }
+            if (e < cold().ps.stack_ovf_entries) cold().ps.stack_ovf[(size_t)e * ovf_stride + uid] = v;
+            else { atomicOr(&cold().ps.counters[kCntError], 1u); return; }
         }
         ++sp;
     };
     auto pop = [&]() -> int32_t {
         if (sp == 0) return PT_BVH_EMPTY;
         --sp;
-        return sp < kStackLds ? s_stack[sp * 64u + lane] : ps.stack_ovf[(size_t)(sp - kStackLds) * ovf_stride + uid];
+        return sp < kStackLds ? s_stack[sp * 64u + lane] : cold().ps.stack_ovf[(size_t)(sp - kStackLds) * ovf_stride + uid];
     };
 
     auto start_ray = [&]() { // the lane's ray is in r.o, r.d
@@ -723,14 +766,15 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
             stash[0 * 64u + lane] = __float_as_uint(r.T.x); stash[1 * 64u + lane] = __float_as_uint(r.T.y);
             stash[2 * 64u + lane] = __float_as_uint(r.T.z); stash[3 * 64u + lane] = r.key;
             stash[4 * 64u + lane] = (r.sample << 8) | r.depth;
+            asm volatile("" ::: "memory"); // no store-to-load forwarding: the values leave the registers
         }
         h = Hit{ __builtin_inff(), PT_MISS, PT_MISS };
-        for (uint32_t j = 0; j < sc.n_spheres; ++j) {
-            sphere_test(sc.spheres[j], sc.n_tris + j, o, d, h);
+        for (uint32_t j = 0; j < n_spheres; ++j) {
+            sphere_test(spheres[j], n_tris + j, o, d, h);
             if (COUNT) c_sph++;
         }
         rs = ray_setup(o, d);
-        cur = sc.n_nodes ? 0 : PT_BVH_EMPTY;
+        cur = n_nodes ? 0 : PT_BVH_EMPTY;
         sp = 0; steps = 0;
     };
 
@@ -740,7 +784,7 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
         bool retired = false, retire_alive = false;
         if (fin) {
             if (FUSE == SHADE_NONE) {
-                ps.hit[slot] = make_float2(h.t, __uint_as_float(h.ref));
+                at(cold().ps.hit, slot) = make_float2(h.t, __uint_as_float(h.ref));
                 has = false;
             } else {
                 r.T = v3(__uint_as_float(stash[0 * 64u + lane]), __uint_as_float(stash[1 * 64u + lane]), __uint_as_float(stash[2 * 64u + lane]));
@@ -748,11 +792,11 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
                 const uint32_t sdv = stash[4 * 64u + lane];
                 r.sample = sdv >> 8; r.depth = sdv & 255u;
                 uint32_t defer = 0u;
-                const bool alive = shade_one<FUSE>(sc, ps, fp, slot, r, h.t, h.ref, B_LAMBERT, defer);
+                const bool alive = shade_one<FUSE>(cold().sc, cold().ps, cold().fp, slot, r, h.t, h.ref, B_LAMBERT, defer);
                 --budget;
                 if (alive && budget != 0u) start_ray(); // next vertex of the same path, state still in registers
                 else {
-                    if (alive) path_store(ps, slot, r);
+                    if (alive) path_store(cold().ps, slot, r);
                     retired = true; retire_alive = alive; has = false;
                 }
             }
@@ -760,7 +804,7 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
         if (FUSE != SHADE_NONE) {
             wave_rays += (uint32_t)__popcll(__ballot(fin && has));
             wave_alive += (uint32_t)__popcll(__ballot(retire_alive));
-            if (do_compact) wave_push(&ps.counters[cnt_ext_index(cnext, shard)], q_next, retire_alive, slot);
+            if (do_compact) wave_push(&cold().ps.counters[cnt_ext_index(cnext, shard)], q_next, retire_alive, slot);
             else if (retired) q_next[pos] = retire_alive ? slot : kInvalidSlot; // the entry keeps its queue position
         }
         // ---- refill idle lanes from the wave's chunk
@@ -773,8 +817,8 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
             if (pull && slot == kInvalidSlot) { // a hole leaves the lane idle until the next refill
                 if (FUSE != SHADE_NONE && !do_compact) q_next[pos] = kInvalidSlot;
             } else if (pull) {
-                if (FUSE == SHADE_NONE) { o = xyz(ps.ray_o[slot]); d = xyz(ps.ray_d[slot]); }
-                else path_load(ps, slot, r);
+                if (FUSE == SHADE_NONE) { o = xyz(at(cold().ps.ray_o, slot)); d = xyz(at(cold().ps.ray_d, slot)); }
+                else path_load(cold().ps, slot, r);
                 budget = budget0;
                 start_ray();
                 has = true;
@@ -792,7 +836,7 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
             if (cur != PT_BVH_EMPTY) {
                 const bool inner = cur >= 0;
                 const uint32_t enc = (uint32_t)~cur, first = enc >> 3, more = enc & 7u;
-                const float4 *base = inner ? sc.nodes + (size_t)cur * node_rows<L>() : sc.tris + (size_t)first * 4;
+                const float4 *base = inner ? nodes + (size_t)cur * node_rows<L>() : tris + (size_t)first * 4;
                 const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
                 const bool deep = __any((int)(sp + (uint32_t)(N - 1) > kStackLds)) != 0; // stack fast path as in k_extend
                 auto pop_fast = [&]() -> int32_t {
@@ -800,7 +844,7 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
                     --sp;
                     return s_stack[sp * 64u + lane];
                 };
-                if (++steps > (1u << 22)) { atomicOr(&ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; }
+                if (++steps > (1u << 22)) { atomicOr(&cold().ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; }
                 else if (inner) {
                     uint32_t key[N];
                     int32_t ref[N];
@@ -835,13 +879,204 @@ k_extend_packed(DeviceScene sc, PathState ps, FrameParams fp, uint32_t it, uint3
         }
     }
     if (COUNT) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(cold().ps.counters + kCntNodes), c_nodes);
+        atomicAdd(reinterpret_cast<unsigned long long *>(cold().ps.counters + kCntTris), c_tris);
+        atomicAdd(reinterpret_cast<unsigned long long *>(cold().ps.counters + kCntSph), c_sph);
+    }
+    if (FUSE != SHADE_NONE && lane == 0u) {
+        if (wave_rays) atomicAdd(traced_counter(cold().ps, cnext, shard), (unsigned long long)wave_rays);
+        if (wave_alive) atomicAdd(&cold().ps.counters[cnt_alive_index(cnext, shard)], wave_alive);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_extend_pool<L, COUNT, FUSE>: the fused pipeline with a per-wavefront ray pool. A wavefront owns kPool (= 64 P) consecutive
+// queue entries — with 8 sample streams, P streams of one 8x8 pixel block — and advances ALL of them by `bounces` path vertices:
+//   traverse : lanes pull rays from the pool (ballot + mbcnt prefix over a live list in LDS) and re-fill whenever
+//              >= kPoolRefill lanes have finished theirs, so a wave's traversal time tends to the pool's MEAN ray length instead
+//              of its longest ray (one ray per lane: 48 % node-loop lane utilisation on the 1M-triangle Cornell box, 12 % on the
+//              soup). While-while with a threshold: lanes at a leaf wait until kPoolLeafWait of them are there (or no lane has a
+//              node left), then their leaves are tested together. Every ray still makes exactly the visits of docs/SPEC.md §4.1 in
+//              exactly that order, so hits and visit counters are the oracle's.
+//   shade    : then the whole pool is shaded P x 64 lanes wide, coalesced in slot order (k_extend_packed shades each ray when
+//              it finishes, i.e. at the width of the refill threshold — that is what made it lose on shallow scenes). Hit
+//              records wait in LDS (8 B per entry); the path state takes one round trip through the slot-indexed arrays per
+//              vertex, which stays in L2 (a pool's state is 6.6 KB), and the new ray's sphere tests are done here, at full width.
+// Same queue contract as k_extend: entry j of the next queue = entry j of this one (slot or hole), or a dense re-pack.
+#ifndef PT_POOL_WAVES
+#define PT_POOL_WAVES(FUSE) ((FUSE) == SHADE_INLINE ? 6 : 7)
+#endif
+#ifndef PT_POOL_REFILL
+#define PT_POOL_REFILL 16
+#endif
+#ifndef PT_POOL_LEAFWAIT
+#define PT_POOL_LEAFWAIT 16
+#endif
+constexpr uint32_t kPoolRefill = PT_POOL_REFILL, kPoolLeafWait = PT_POOL_LEAFWAIT;
+
+template <int L, bool COUNT, int FUSE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_POOL_WAVES(FUSE), PT_POOL_WAVES(FUSE)))) k_extend_pool(ExtArgs a)
+{
+    static_assert(FUSE != SHADE_NONE, "the pool kernel always shades");
+    constexpr uint32_t E = kPool, P = E / 64u;
+    static_assert(E % 64u == 0 && E >= 64u && E <= 256u, "kPool: 64, 128, 192 or 256 (live list holds byte indices)");
+    const float4 *__restrict__ nodes = a.sc.nodes, *__restrict__ tris = a.sc.tris, *__restrict__ spheres = a.sc.spheres;
+    const uint32_t n_spheres = a.sc.n_spheres, n_tris = a.sc.n_tris, n_nodes = a.sc.n_nodes;
+    const uint32_t it = a.it;
+    const uint32_t parity = it & 1u, ccur = it % 3u, cnext = (it + 1u) % 3u, czero = (it + 2u) % 3u;
+    __shared__ int32_t s_stack[kStackLds * 64];
+    __shared__ float s_ht[E];       // per pool entry: closest hit so far (before traversal: of the sphere list), t
+    __shared__ uint32_t s_href[E];  //                 ... and its primitive ref
+    __shared__ uint32_t s_slot[E];  // slot of the entry, kInvalidSlot once its path and stream have ended
+    __shared__ uint8_t s_live[E];   // entries that hold a ray for the coming traversal, densely
+    uint32_t shard, bx, nbx;
+    block_pos(a.ps, shard, bx, nbx);
+    const uint32_t lane = threadIdx.x;
+    uint32_t n, n_alive, n_bounces;
+    bool do_compact;
+    size_t qbase;
+    {
+        const PathState &ps = cold().ps;
+        n = ps.counters[cnt_ext_index(ccur, shard)]; n_alive = ps.counters[cnt_alive_index(ccur, shard)];
+        do_compact = want_compact(ps, n, n_alive, a.compact != 0u);
+        if (bx == 0 && lane == 0) {
+            ps.counters[cnt_ext_index(czero, shard)] = 0u;
+            ps.counters[cnt_alive_index(czero, shard)] = 0u;
+            fold_traced(ps, shard, it);
+            if (!do_compact) ps.counters[cnt_ext_index(cnext, shard)] = n; // carried in place: the length stays
+            if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
+        }
+        if (bx * E >= n || n_alive == 0u) return;
+        qbase = (size_t)shard * ps.shard_cap;
+        n_bounces = n_alive <= ps.finish_below ? kFinishVertices : a.bounces;
+    }
+    const StackCtx stk{ s_stack, 64u, lane, (uint32_t)qbase + bx * 64u + lane };
+    unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0, c_wave_iters = 0;
+
+    auto spheres_of = [&](V3 o, V3 d, uint32_t e) { // the sphere list is tested when a ray is made (full width); traversal starts from its result
+        Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
+        for (uint32_t j = 0; j < n_spheres; ++j) sphere_test(spheres[j], n_tris + j, o, d, h); // uniform index => scalar loads
+        s_ht[e] = h.t; s_href[e] = h.ref;
+    };
+    auto live_append = [&](bool pred, uint32_t e, uint32_t &count) {
+        const uint64_t m = __ballot(pred);
+        if (pred) s_live[count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint8_t)e;
+        count += (uint32_t)__popcll(m);
+    };
+
+    // ---- the pool: queue entries -> slots, sphere tests of the rays they hold, live list
+    uint32_t n_live = 0;
+    {
+        const PathState &ps = cold().ps;
+#pragma unroll
+        for (uint32_t hh = 0; hh < P; ++hh) {
+            const uint32_t e = hh * 64u + lane, g = bx * E + e;
+            const uint32_t slot = g < n ? ps.q_ext[parity][qbase + g] : kInvalidSlot;
+            s_slot[e] = slot;
+            const bool valid = slot != kInvalidSlot;
+            if (valid) spheres_of(xyz(at(ps.ray_o, slot)), xyz(at(ps.ray_d, slot)), e);
+            live_append(valid, e, n_live);
+        }
+    }
+    __syncthreads();
+
+    uint32_t wave_rays = 0;
+    for (uint32_t bounce = 0; bounce < n_bounces && n_live; ++bounce) {
+        wave_rays += n_live;
+        // ---- traverse the pool
+        uint32_t next = 0, e = 0, sp = 0, steps = 0;
+        bool has = false;
+        int32_t cur = PT_BVH_EMPTY;
+        V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
+        RaySetup rs = ray_setup(o, d);
+        Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
+        for (;;) {
+            if (has && cur == PT_BVH_EMPTY) { s_ht[e] = h.t; s_href[e] = h.ref; has = false; } // finished: hit record to the pool
+            const uint64_t idle = __ballot(!has);
+            const uint32_t avail = n_live - next;
+            if (idle && avail) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (!has && prefix < avail) {
+                    const PathState &ps = cold().ps;
+                    e = s_live[next + prefix];
+                    const uint32_t slot = s_slot[e];
+                    o = xyz(at(ps.ray_o, slot)); d = xyz(at(ps.ray_d, slot));
+                    const uint32_t ref0 = s_href[e];
+                    h = Hit{ s_ht[e], ref0, ref0 }; // spheres: id == ref (docs/SPEC.md §3); miss: both PT_MISS
+                    cur = n_nodes ? 0 : PT_BVH_EMPTY;
+                    rs = ray_setup(o, d);
+                    sp = 0; steps = 0; has = true;
+                    if (COUNT) c_sph += n_spheres;
+                }
+                next += min((uint32_t)__popcll(idle), avail);
+            }
+            if (!__ballot(has)) break;
+            for (;;) {
+                const bool is_n = has && (uint32_t)cur < (uint32_t)PT_BVH_EMPTY, is_l = has && cur < 0;
+                const uint64_t m_n = __ballot(is_n), m_l = __ballot(is_l);
+                if (!(m_n | m_l)) break;
+                const uint32_t n_l = (uint32_t)__popcll(m_l), busy = (uint32_t)__popcll(m_n) + n_l;
+                if (next < n_live && 64u - busy >= kPoolRefill) break; // enough lanes can take a new ray
+                if (m_l && (!m_n || n_l >= kPoolLeafWait)) {
+                    if (is_l) { const uint32_t nt = leaf_step(tris, stk, o, d, h, cur, sp); if (COUNT) c_tris += nt; }
+                } else if (is_n) {
+                    if (++steps > (1u << 22)) { atomicOr(&cold().ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; }
+                    else {
+                        if (COUNT) { c_nodes++; if (lane == (uint32_t)(__ffsll((long long)m_n) - 1)) c_wave_iters++; }
+                        node_step<L>(nodes, stk, rs, h.t, cur, sp);
+                    }
+                }
+            }
+        }
+        __syncthreads(); // every hit record is in LDS
+
+        // ---- shade the pool, P x 64 lanes wide, in slot order
+        const bool last = bounce + 1u == n_bounces;
+        uint32_t n_next = 0;
+        const ExtArgs &c = cold();
+#pragma unroll
+        for (uint32_t hh = 0; hh < P; ++hh) {
+            const uint32_t e2 = hh * 64u + lane;
+            const uint32_t slot = s_slot[e2];
+            bool alive = false;
+            if (slot != kInvalidSlot) {
+                PathRegs r;
+                path_load(c.ps, slot, r);
+                uint32_t defer = 0u;
+                alive = shade_one<FUSE>(c.sc, c.ps, c.fp, slot, r, s_ht[e2], s_href[e2], B_LAMBERT, defer);
+                if (alive) {
+                    path_store(c.ps, slot, r);
+                    if (!last) spheres_of(r.o, r.d, e2);
+                } else s_slot[e2] = kInvalidSlot;
+            }
+            live_append(alive, e2, n_next);
+        }
+        n_live = n_next;
+        __syncthreads(); // the new rays (global) and the live list (LDS) are visible to whichever lane pulls them
+    }
+
+    // ---- hand the survivors to the next iteration
+    const PathState &ps = cold().ps;
+    uint32_t *q_next = ps.q_ext[parity ^ 1u] + qbase;
+    uint32_t n_left = 0;
+#pragma unroll
+    for (uint32_t hh = 0; hh < P; ++hh) {
+        const uint32_t e2 = hh * 64u + lane, g = bx * E + e2;
+        const uint32_t slot = s_slot[e2];
+        const bool alive = slot != kInvalidSlot;
+        if (do_compact) wave_push(&ps.counters[cnt_ext_index(cnext, shard)], q_next, alive, slot);
+        else if (g < n) q_next[g] = slot;
+        n_left += (uint32_t)__popcll(__ballot(alive));
+    }
+    if (COUNT) {
+        if (c_wave_iters) atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntWaveNodeIters), c_wave_iters);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);
     }
-    if (FUSE != SHADE_NONE && lane == 0u) {
+    if (lane == 0u) {
         if (wave_rays) atomicAdd(traced_counter(ps, cnext, shard), (unsigned long long)wave_rays);
-        if (wave_alive) atomicAdd(&ps.counters[cnt_alive_index(cnext, shard)], wave_alive);
+        if (n_left) atomicAdd(&ps.counters[cnt_alive_index(cnext, shard)], n_left);
     }
 }
 
@@ -888,7 +1123,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
     uint32_t defer = 0u; // SPEC == false: bucket this lane's hit must be shaded in (0 = handled here)
 
     if (active) {
-        const float2 hr = ps.hit[slot];
+        const float2 hr = at(ps.hit, slot);
         PathRegs r;
         path_load(ps, slot, r);
         alive = shade_one<MODE>(sc, ps, fp, slot, r, hr.x, __float_as_uint(hr.y), b, defer);
@@ -957,32 +1192,35 @@ hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState
 }
 
 template <int L, bool C>
-static void extend_lc(hipStream_t s, dim3 grid, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t chunk, int fuse,
-                      uint32_t cm, uint32_t bounces)
+static void extend_lc(hipStream_t s, dim3 grid, const ExtArgs &a, int kernel, int fuse)
 {
-    if (chunk && fuse == SHADE_QUEUE) hipLaunchKernelGGL((k_extend_packed<L, C, SHADE_QUEUE>), grid, dim3(64), 0, s, sc, ps, fp, it, chunk, cm, bounces);
-    else if (chunk && fuse == SHADE_INLINE) hipLaunchKernelGGL((k_extend_packed<L, C, SHADE_INLINE>), grid, dim3(64), 0, s, sc, ps, fp, it, chunk, cm, bounces);
-    else if (chunk) hipLaunchKernelGGL((k_extend_packed<L, C, SHADE_NONE>), grid, dim3(64), 0, s, sc, ps, fp, it, chunk, cm, bounces);
-    else if (fuse == SHADE_QUEUE) hipLaunchKernelGGL((k_extend<L, C, SHADE_QUEUE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm, bounces);
-    else if (fuse == SHADE_INLINE) hipLaunchKernelGGL((k_extend<L, C, SHADE_INLINE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm, bounces);
-    else hipLaunchKernelGGL((k_extend<L, C, SHADE_NONE>), grid, dim3(kExtBlock), 0, s, sc, ps, fp, it, cm, bounces);
+    if (kernel == EXT_POOL && fuse == SHADE_INLINE) hipLaunchKernelGGL((k_extend_pool<L, C, SHADE_INLINE>), grid, dim3(64), 0, s, a);
+    else if (kernel == EXT_POOL) hipLaunchKernelGGL((k_extend_pool<L, C, SHADE_QUEUE>), grid, dim3(64), 0, s, a);
+    else if (kernel == EXT_PACKED && fuse == SHADE_QUEUE) hipLaunchKernelGGL((k_extend_packed<L, C, SHADE_QUEUE>), grid, dim3(64), 0, s, a);
+    else if (kernel == EXT_PACKED && fuse == SHADE_INLINE) hipLaunchKernelGGL((k_extend_packed<L, C, SHADE_INLINE>), grid, dim3(64), 0, s, a);
+    else if (kernel == EXT_PACKED) hipLaunchKernelGGL((k_extend_packed<L, C, SHADE_NONE>), grid, dim3(64), 0, s, a);
+    else if (fuse == SHADE_QUEUE) hipLaunchKernelGGL((k_extend<L, C, SHADE_QUEUE>), grid, dim3(kExtBlock), 0, s, a);
+    else if (fuse == SHADE_INLINE) hipLaunchKernelGGL((k_extend<L, C, SHADE_INLINE>), grid, dim3(kExtBlock), 0, s, a);
+    else hipLaunchKernelGGL((k_extend<L, C, SHADE_NONE>), grid, dim3(kExtBlock), 0, s, a);
 }
 
 hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t shard_bound, bool count,
-                         uint32_t packed_chunk, int fuse, bool compact, uint32_t bounces)
+                         int kernel, uint32_t packed_chunk, int fuse, bool compact, uint32_t bounces)
 {
-    const uint32_t nb = bounces ? bounces : 1u;
-    // packed_chunk >= 64: rays per wavefront of the lane-packing kernel (PT_FLAG_EXTEND_PACKED); 0: one ray per lane.
-    // Measured on MI355X: packing raises lane utilisation but is slower at every chunk size, because the
-    // kernel is bound by outstanding divergent node fetches and fewer waves means fewer of them; it stays selectable.
-    const uint32_t chunk = packed_chunk >= 64u ? packed_chunk : 0u, per_block = chunk ? chunk : kExtBlock;
+    // kernel: EXT_SIMPLE one ray per lane; EXT_PACKED a wavefront owns `packed_chunk` (>= 64) queue entries and refills idle lanes,
+    // shading each finished ray on the spot; EXT_POOL a wavefront owns kPool entries, refills idle lanes during traversal and shades
+    // the whole pool at full width (fused only: without shading it falls back to EXT_PACKED).
+    if (kernel == EXT_POOL && fuse == SHADE_NONE) kernel = EXT_PACKED;
+    const uint32_t chunk = kernel == EXT_PACKED ? (packed_chunk >= 64u ? packed_chunk : 128u) : 0u;
+    const uint32_t per_block = kernel == EXT_PACKED ? chunk : kernel == EXT_POOL ? kPool : kExtBlock;
     const dim3 grid = shard_grid(shard_bound ? (shard_bound + per_block - 1) / per_block : 1u, ps.shard_count);
-    const uint32_t cm = compact ? 1u : 0u;
+    ExtArgs a;
+    a.sc = sc; a.ps = ps; a.fp = fp; a.it = it; a.compact = compact ? 1u : 0u; a.bounces = bounces ? bounces : 1u; a.chunk = chunk;
     switch (sc.bvh_width) {
-    case PT_BVH_WIDTH_2:  count ? extend_lc<PT_BVH_WIDTH_2, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_2, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
-    case PT_BVH_WIDTH_4:  count ? extend_lc<PT_BVH_WIDTH_4, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_4, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
-    case PT_BVH_WIDTH_4Q: count ? extend_lc<PT_BVH_WIDTH_4Q, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_4Q, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
-    case PT_BVH_WIDTH_8Q: count ? extend_lc<PT_BVH_WIDTH_8Q, true>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb) : extend_lc<PT_BVH_WIDTH_8Q, false>(s, grid, sc, ps, fp, it, chunk, fuse, cm, nb); break;
+    case PT_BVH_WIDTH_2:  count ? extend_lc<PT_BVH_WIDTH_2, true>(s, grid, a, kernel, fuse) : extend_lc<PT_BVH_WIDTH_2, false>(s, grid, a, kernel, fuse); break;
+    case PT_BVH_WIDTH_4:  count ? extend_lc<PT_BVH_WIDTH_4, true>(s, grid, a, kernel, fuse) : extend_lc<PT_BVH_WIDTH_4, false>(s, grid, a, kernel, fuse); break;
+    case PT_BVH_WIDTH_4Q: count ? extend_lc<PT_BVH_WIDTH_4Q, true>(s, grid, a, kernel, fuse) : extend_lc<PT_BVH_WIDTH_4Q, false>(s, grid, a, kernel, fuse); break;
+    case PT_BVH_WIDTH_8Q: count ? extend_lc<PT_BVH_WIDTH_8Q, true>(s, grid, a, kernel, fuse) : extend_lc<PT_BVH_WIDTH_8Q, false>(s, grid, a, kernel, fuse); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -164,25 +164,26 @@ PT_DEV V3 reflect_about(V3 d, V3 n, float cosi)
 }
 PT_DEV float clamp01(float x) { return fmin_(fmax_(x, 0.0f), 1.0f); }
 
-PT_DEV void sample_lambert(V3 alb, V3 n, float u1, float u2, V3 &wi, V3 &W)
+// What a BSDF sampler returns (by value: outputs through references ended up in a scratch array once the three samplers met
+// in one branch of shade_one): direction, throughput weight, side of the surface the next ray leaves from, validity.
+struct BsdfSample { V3 wi, W; float side; bool ok; };
+
+PT_DEV BsdfSample sample_lambert(V3 alb, V3 n, float u1, float u2)
 {
+    V3 wi;
     V3 tx, ty;
     basis(n, tx, ty);
     float r = __builtin_sqrtf(u1), sn, cs;
     sincos2pi(u2, sn, cs);
     V3 l = V3{ r * cs, r * sn, __builtin_sqrtf(fmax_(0.0f, 1.0f - u1)) };
     wi = to_world(l, tx, ty, n);
-    W = alb;
+    return BsdfSample{ wi, alb, 1.0f, true };
 }
 
-PT_DEV bool sample_metal(V3 alb, float al, V3 d, V3 n, float u1, float u2, V3 &wi, V3 &W)
+PT_DEV BsdfSample sample_metal(V3 alb, float al, V3 d, V3 n, float u1, float u2)
 {
     float cosi = clamp01(-dot(d, n));
-    if (al == 0.0f) {
-        wi = reflect_about(d, n, cosi);
-        W = schlick(alb, cosi);
-        return true;
-    }
+    if (al == 0.0f) return BsdfSample{ reflect_about(d, n, cosi), schlick(alb, cosi), 1.0f, true };
     V3 tx, ty;
     basis(n, tx, ty);
     V3 wo = neg(d);
@@ -205,17 +206,17 @@ PT_DEV bool sample_metal(V3 alb, float al, V3 d, V3 n, float u1, float u2, V3 &w
     float cosF = clamp01(dh);
     float c2 = 2.0f * dh;
     V3 wil = V3{ fma_(c2, hh.x, -wl.x), fma_(c2, hh.y, -wl.y), fma_(c2, hh.z, -wl.z) };
-    if (!(wil.z > 0.0f)) return false;
+    if (!(wil.z > 0.0f)) return BsdfSample{ d, alb, 1.0f, false };
     float wz = wil.z;
     float G1 = 2.0f * wz / (wz + __builtin_sqrtf(fma_(al * al, 1.0f - wz * wz, wz * wz)));
     V3 F = schlick(alb, cosF);
-    W = V3{ F.x * G1, F.y * G1, F.z * G1 };
-    wi = to_world(wil, tx, ty, n);
-    return true;
+    return BsdfSample{ to_world(wil, tx, ty, n), V3{ F.x * G1, F.y * G1, F.z * G1 }, 1.0f, true };
 }
 
-PT_DEV void sample_dielectric(V3 alb, float ior, V3 d, V3 n, bool front, float u3, V3 &wi, V3 &W, float &side)
+PT_DEV BsdfSample sample_dielectric(V3 alb, float ior, V3 d, V3 n, bool front, float u3)
 {
+    V3 wi;
+    float side;
     float cosi = clamp01(-dot(d, n));
     float eta = front ? 1.0f / ior : ior;
     float sin2t = eta * eta * (1.0f - cosi * cosi);
@@ -236,7 +237,7 @@ PT_DEV void sample_dielectric(V3 alb, float ior, V3 d, V3 n, bool front, float u
         wi = normalize(V3{ fma_(k, n.x, eta * d.x), fma_(k, n.y, eta * d.y), fma_(k, n.z, eta * d.z) });
         side = -1.0f;
     }
-    W = alb;
+    return BsdfSample{ wi, alb, side, true };
 }
 
 // ---------------------------------------------------------------- SPEC §1 the reference's kernel

@@ -19,6 +19,11 @@ constexpr uint32_t kBlock = 256;                   // threads per workgroup = 4 
 constexpr uint32_t kStackLds = PT_STACK_LDS;       // traversal-stack entries kept in LDS per lane
 constexpr uint32_t kExtBlock = PT_EXT_BLOCK;       // workgroup size of k_extend (a wave retires on its own when it is 64)
 constexpr uint32_t kMaxSpheres = 64;
+#ifndef PT_POOL
+#define PT_POOL 128
+#endif
+constexpr uint32_t kPool = PT_POOL;                // queue entries per wavefront of k_extend_pool (64 P)
+enum ExtendKernel : int { EXT_SIMPLE = 1, EXT_PACKED = 2, EXT_POOL = 3 }; // pt_stats.reserved[0]
 
 // Queue sharding. A slot belongs to shard (slot >> 8) % kShards for the whole frame, every queue is kShards
 // independent regions of `shard_cap` entries with one counter line each, and a workgroup works on exactly one shard
@@ -105,11 +110,11 @@ struct FrameParams {
 hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4 *out_f, uint32_t *out_rgba8);
 hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp);
 // `it` = iteration index of the wavefront loop: queues alternate by it & 1, queue counters rotate by it % 3.
-// fuse: -1 = extend only (k_shade follows); 0 / 2 = k_extend also shades (Lambert-only / all kinds) and queues the next
-// iteration, honouring `compact` like launch_shade. Ignored (treated as -1) by the lane-packing kernel.
-// bounces (fused only): path vertices a lane advances per launch with its path state in registers.
+// kernel: ExtendKernel. fuse: -1 = extend only (k_shade follows); 0 / 2 = the kernel also shades (Lambert-only / all kinds) and
+// queues the next iteration, honouring `compact` like launch_shade. packed_chunk: queue entries per wavefront of EXT_PACKED.
+// bounces (fused only): path vertices a lane advances per launch.
 hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t it, uint32_t shard_bound, bool count,
-                         uint32_t packed_chunk, int fuse, bool compact, uint32_t bounces);
+                         int kernel, uint32_t packed_chunk, int fuse, bool compact, uint32_t bounces);
 // mode: 0 = queue order, specular kinds deferred to buckets; 1 = the specular buckets; 2 = queue order, everything shaded in place
 // compact: 1 = survivors are appended densely to the next queue (ballot + one returning atomic per wavefront);
 //          0 = every lane writes its own position of the next queue (slot or kInvalidSlot): no returning atomics, and the

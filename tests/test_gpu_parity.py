@@ -98,6 +98,28 @@ def test_packed_extend_kernel_is_identical(P, pto, renderer):
     assert_parity(*run_both(P, pto, renderer, sd, p, 2))
 
 
+def test_pool_extend_kernel_is_identical(P, pto, renderer):
+    """PT_FLAG_EXTEND_POOL (a wavefront owns 128 queue entries, refills idle lanes while it traverses, shades the pool at full
+    width) must not change a single bit nor a single visit count — on every node layout, with holes, streams and deep paths."""
+    N = P.native
+    for width in (2, 4, 68, 72):
+        sd = P.make_scene(N.PT_SCENE_TRIANGLE_SOUP, 30000, 3, 200, 150)
+        p = P.make_params(200, 150, spp=5, max_depth=8, streams=3, flags=N.PT_FLAG_EXTEND_POOL)
+        img, st, ref, ost = run_both(P, pto, renderer, sd, p, width, count=True)
+        assert st.reserved[0] == 3
+        assert_parity(img, st, ref, ost)
+        assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests)
+    sd = P.make_scene(N.PT_SCENE_CORNELL_GLASS, 0, 3, 130, 70)
+    for streams, spp in ((1, 3), (8, 11)):
+        p = P.make_params(130, 70, spp=spp, max_depth=12, streams=streams, flags=N.PT_FLAG_EXTEND_POOL)
+        assert_parity(*run_both(P, pto, renderer, sd, p, 0))
+    sd = P.make_scene(N.PT_SCENE_CORNELL_TESS, 60000, 7, 333, 97)
+    p = P.make_params(333, 97, spp=9, max_depth=8, streams=8, flags=N.PT_FLAG_EXTEND_POOL)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, p, 0, count=True)
+    assert_parity(img, st, ref, ost)
+    assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests)
+
+
 def test_c5_tessellated_cornell(P, pto, renderer):
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_TESS, 60000, 0x5EED0001, 160, 120)
     img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(160, 120, spp=4, max_depth=8), 4)
@@ -311,7 +333,7 @@ def test_shard_groups_on_separate_streams(P, pto, monkeypatch):
     assert all(f[0] == frames[0][0] and np.array_equal(f[1], frames[0][1]) for f in frames)
 
 
-@pytest.mark.parametrize("flags", [0, 4, 64, 68])  # fused one-ray-per-lane / lane-packing kernels, and each followed by k_shade (PT_FLAG_SPLIT_KERNELS)
+@pytest.mark.parametrize("flags", [0, 4, 128, 64, 68])  # fused one-ray-per-lane / lane-packing / pooled kernels, and the first two followed by k_shade (PT_FLAG_SPLIT_KERNELS)
 def test_queue_compaction_policy_is_invisible(P, pto, monkeypatch, flags):
     """PTRT_COMPACT: queues carried over in place with holes (0 = never re-packed), re-packed every iteration (2), or
     re-packed when alive/length < 0.9 — scheduling only: frame and ray count stay the oracle's. The streams end at
@@ -336,11 +358,12 @@ def test_queue_compaction_policy_is_invisible(P, pto, monkeypatch, flags):
     assert frames[0][2] == 0 and frames[1][2] > frames[2][2] > 0  # (shard, iteration) pairs that re-packed
 
 
-def test_bounces_per_launch_is_invisible(P, pto, monkeypatch):
+@pytest.mark.parametrize("kflag", [8, 128])  # one ray per lane, pooled
+def test_bounces_per_launch_is_invisible(P, pto, monkeypatch, kflag):
     """PTRT_BOUNCES: the fused kernel advances a path by 1, 3 or 16 vertices per launch with its state in registers
     (kernels.hip k_extend). Same arithmetic per vertex, so frame, ray count and visit counters stay the oracle's."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 4, 160, 120)
-    p = P.make_params(160, 120, spp=5, max_depth=9, streams=2, flags=P.native.PT_FLAG_COUNT_VISITS)
+    p = P.make_params(160, 120, spp=5, max_depth=9, streams=2, flags=P.native.PT_FLAG_COUNT_VISITS | kflag)
     got = []
     # PTRT_FINISH: shards with no more alive paths than this run them to their end in one launch (0 = never, 1000000 = always)
     for b, finish in (("1", "0"), ("3", "0"), ("16", "0"), ("2", "1000000")):
@@ -389,14 +412,14 @@ def test_randomised_configurations_against_the_oracle(P, pto, renderer):
     N = P.native
     rng = np.random.default_rng(20261005)
     kinds = [(N.PT_SCENE_CORNELL, 0), (N.PT_SCENE_CORNELL_GLASS, 0), (N.PT_SCENE_TRIANGLE_SOUP, 3000), (N.PT_SCENE_CORNELL_TESS, 2500)]
-    for case in range(40):
+    for case in range(60):
         kind, detail = kinds[int(rng.integers(len(kinds)))]
         w, h = int(rng.integers(1, 150)), int(rng.integers(1, 110))
         spp, depth = int(rng.integers(1, 12)), int(rng.integers(1, 14))
         streams = int(rng.choice([0, 1, 2, 3, 8, 16]))
         width = int(rng.choice([0, 2, 4, 68, 72]))
-        flags = int(rng.choice([0, 0, N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_EXTEND_SIMPLE, N.PT_FLAG_SPLIT_KERNELS,
-                                N.PT_FLAG_SPLIT_KERNELS | N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_BUCKET_SPECULAR]))
+        flags = int(rng.choice([0, 0, N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_EXTEND_SIMPLE, N.PT_FLAG_EXTEND_POOL, N.PT_FLAG_EXTEND_POOL,
+                                N.PT_FLAG_SPLIT_KERNELS, N.PT_FLAG_SPLIT_KERNELS | N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_BUCKET_SPECULAR]))
         offset = int(rng.integers(0, 5))
         sd = P.make_scene(kind, detail, int(rng.integers(1, 1 << 30)), w, h)
         p = P.make_params(w, h, spp=spp, max_depth=depth, streams=streams, flags=flags, sample_offset=offset, seed=int(rng.integers(1 << 31)))
