@@ -426,6 +426,7 @@ static void trace_pixel(const pto_scene *s, const pto_params *p, uint32_t x, uin
             depth++;
             if (h.id == PTO_MISS) {
                 for (int k = 0; k < 3; ++k) acc[k] = fma_(T[k], s->sky[k], acc[k]);
+                if (depth == 1) st->primary_misses++;
                 break;
             }
             v3 P = madd3(h.t, d, o), ng;
@@ -505,7 +506,7 @@ int pto_render(const pto_scene *s, const pto_params *p, int threads, float *rgba
 #pragma omp critical
         {
             tot.rays += loc.rays; tot.paths += loc.paths; tot.node_visits += loc.node_visits;
-            tot.tri_tests += loc.tri_tests; tot.sphere_tests += loc.sphere_tests;
+            tot.tri_tests += loc.tri_tests; tot.sphere_tests += loc.sphere_tests; tot.primary_misses += loc.primary_misses;
         }
     }
     if (st) *st = tot;

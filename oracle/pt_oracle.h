@@ -49,7 +49,10 @@ typedef struct {
     uint32_t bvh_width, n_nodes; const void *nodes; const void *tris48;
 } pto_scene;
 
-typedef struct { uint64_t rays, paths, node_visits, tri_tests, sphere_tests; } pto_stats;
+typedef struct {
+    uint64_t rays, paths, node_visits, tri_tests, sphere_tests;
+    uint64_t primary_misses; /* paths whose camera ray hits nothing (one ray, straight into the sky) */
+} pto_stats;
 
 /* SPEC §1. rgba (W*H*4 floats) and/or rgba8 (W*H*4 bytes) may be NULL. */
 int pto_reference_sphere(uint32_t w, uint32_t h, float *rgba, uint8_t *rgba8);

@@ -40,7 +40,7 @@ class pto_scene(C.Structure):
 
 class pto_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("sphere_tests", C.c_uint64)]
+                ("sphere_tests", C.c_uint64), ("primary_misses", C.c_uint64)]
 
 
 lib.pto_reference_sphere.restype = C.c_int

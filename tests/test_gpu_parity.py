@@ -150,6 +150,26 @@ def test_1m_triangles_full_hd_properties(P, pto, renderer):
     assert rmse(img, ref) <= RMSE_TOL and np.array_equal(img, ref)
 
 
+def test_headline_configuration_as_benchmarked(P, pto, renderer):
+    """The configuration bench.py times, exactly: 1M-triangle Cornell, 1920x1080, 64 spp, 8 sample streams, max depth 8, default
+    node layout and default extend-kernel choice (probed). Frame bit-identical to the oracle, ray count equal."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_TESS, 1 << 20, 0x5EED0001, 1920, 1080)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(1920, 1080, spp=64, max_depth=8, streams=8), 0)
+    assert renderer.BvhInfo().width == 68
+    assert_parity(img, st, ref, ost)
+    assert st.paths == 1920 * 1080 * 64 and (img[..., 3] == 1.0).all()
+    st2 = renderer.Render(0.0)  # the second frame runs with the kernel the first one picked
+    assert st2.rays == st.rays and np.array_equal(renderer.ReadFramebuffer(), ref)
+
+
+def test_c4_at_its_real_depth_and_spp(P, pto, renderer):
+    """BASELINE configs[3] (Cornell + glass + rough metal) at its real 256 spp and max depth 16, on a 480x270 frame."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, 480, 270)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(480, 270, spp=256, max_depth=16, streams=8), 0)
+    assert renderer.BvhInfo().width == 72
+    assert_parity(img, st, ref, ost)
+
+
 def test_4k_frame_and_full_hd_soup(P, pto, renderer):
     """BASELINE configs[4] frame size (3840x2160, 1M-triangle Cornell) and configs[2] (1M-triangle soup, 1080p) at 1 spp,
     8 streams allocated: the largest slot spaces the benchmark configurations use, against the oracle."""
