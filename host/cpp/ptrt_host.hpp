@@ -4,6 +4,7 @@
 #pragma once
 #include "../../include/ptrt.h"
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -72,6 +73,8 @@ public:
         if (ctx_) pt_context_destroy(ctx_);
         scene_ = nullptr; ctx_ = nullptr;
     }
+    pt_context *Context() const { return ctx_; }
+    pt_scene *Scene() const { return scene_; }
 
 private:
     void ComputeFrame(float) // Renderer.cs:1006-1040 + fence wait :972
@@ -80,6 +83,59 @@ private:
     }
     pt_context *ctx_ = nullptr;
     pt_scene *scene_ = nullptr;
+};
+
+// One frame over several GPUs of the node (include/ptrt.h pt_comm): a Renderer per device, the same scene committed on each, tiles
+// dealt round-robin, one ncclGather per frame inside libptrt. `virtual_ranks`: every rank on device 0 through one Renderer
+// (rehearsal on a single GPU). The reference is single-device; this is what stands above its Renderer when a node has 8 GPUs.
+class MultiRenderer {
+public:
+    pt_render_params Params{};
+    std::vector<pt_stats> LastStats;
+
+    MultiRenderer(uint32_t n_ranks, uint32_t width, uint32_t height, bool virtual_ranks = false) : n_(n_ranks), virtual_(virtual_ranks)
+    {
+        const uint32_t n_ctx = virtual_ ? 1u : n_;
+        for (uint32_t i = 0; i < n_ctx; ++i) r_.emplace_back(new Renderer(width, height));
+        Params = r_[0]->Params;
+    }
+    MultiRenderer(const MultiRenderer &) = delete;
+    ~MultiRenderer() { Dispose(); }
+    void Init()
+    {
+        for (size_t i = 0; i < r_.size(); ++i) r_[i]->Init((int)i);
+    }
+    void LoadSyntheticScene(uint32_t kind, uint32_t detail = 0, uint32_t seed = 0x5EED0001u, uint32_t bvh_width = 0)
+    {
+        for (auto &r : r_) r->LoadSyntheticScene(kind, detail, seed, bvh_width); // replicated scene
+        Params.mode = PT_PATH_TRACE;
+        std::vector<pt_context *> ctxs(n_);
+        for (uint32_t i = 0; i < n_; ++i) ctxs[i] = r_[virtual_ ? 0 : i]->Context();
+        if (comm_) pt_comm_destroy(comm_);
+        comm_ = nullptr;
+        check(pt_comm_create(ctxs.data(), n_, 0, 0, &comm_));
+    }
+    void Render(float)
+    {
+        std::vector<const pt_scene *> scenes(n_);
+        for (uint32_t i = 0; i < n_; ++i) scenes[i] = r_[virtual_ ? 0 : i]->Scene();
+        LastStats.assign(n_, pt_stats{});
+        check(pt_comm_render(comm_, scenes.data(), &Params, LastStats.data()), r_[0]->Context());
+        r_[0]->Params = Params;
+    }
+    Renderer &Root() { return *r_[0]; }
+    void Dispose()
+    {
+        if (comm_) pt_comm_destroy(comm_);
+        comm_ = nullptr;
+        r_.clear();
+    }
+
+private:
+    uint32_t n_;
+    bool virtual_;
+    std::vector<std::unique_ptr<Renderer>> r_;
+    pt_comm *comm_ = nullptr;
 };
 
 } // namespace ptrt_host

@@ -23,14 +23,14 @@ public class HeadlessApp : IDisposable
         f.Write(System.Text.Encoding.ASCII.GetBytes($"P6\n{Renderer.Width} {Renderer.Height}\n255\n"));
         for (int i = 0; i < px.Length; i += 4) f.Write(px, i, 3);
         PtStats s = Renderer.LastStats;
-        Console.WriteLine($"{s.Rays} rays, {s.GpuMs:F2} ms, {s.Rays / s.GpuMs / 1e3:F1} Mrays/s -> {Output}");
+        Console.WriteLine($"{s.rays} rays, {s.gpu_ms:F2} ms, {s.rays / s.gpu_ms / 1e3:F1} Mrays/s -> {Output}");
     }
 
     private void InitRenderer()
     {
         Renderer = new HipRenderer();
         Renderer.Init();
-        if (Scene is PtSceneKind k) { Renderer.LoadSyntheticScene(k, Detail); Renderer.Params.Spp = Spp; }
+        if (Scene is PtSceneKind k) { Renderer.LoadSyntheticScene(k, Detail); Renderer.Params.spp = Spp; }
     }
 
     public void Dispose() { Renderer?.Dispose(); GC.SuppressFinalize(this); }

@@ -16,37 +16,37 @@ public unsafe class HipRenderer : IDisposable
     public HipRenderer(uint width = 1920, uint height = 1080) // App.cs:27 window size
     {
         Width = width; Height = height;
-        Params = new PtRenderParams { Width = width, Height = height, Spp = 1, MaxDepth = 8, RrStart = 3, Seed = 0x5EED0001,
-                                      Mode = (uint)PtMode.ReferenceSphere, RayEps = 1e-4f, NRanks = 1, Streams = 8 };
+        Params = new PtRenderParams { width = width, height = height, spp = 1, max_depth = 8, rr_start = 3, seed = 0x5EED0001,
+                                      mode = (uint)PtMode.ReferenceSphere, ray_eps = 1e-4f, nranks = 1, streams = 8 };
     }
 
     // Renderer.Init (Renderer.cs:66-84): device + resources + compute pipeline
     public void Init(int device = 0)
     {
-        PtDeviceDesc d = new() { DeviceOrdinal = device };
+        PtDeviceDesc d = new() { device_ordinal = device };
         void* c; Ptrt.Check(Ptrt.pt_context_create(&d, &c)); _ctx = c;
     }
 
     public void LoadSyntheticScene(PtSceneKind kind, uint detail = 0, uint seed = 0x5EED0001, uint bvhWidth = 0)
     {
         PtSceneCounts n; PtCamera cam; float* sky = stackalloc float[3];
-        Ptrt.Check(Ptrt.pt_scenegen(kind, detail, seed, Width, Height, &n, null, null, null, null, null, null, null));
-        float[] verts = new float[n.NTris * 9]; uint[] tmat = new uint[n.NTris];
-        float[] sph = new float[Math.Max(1, n.NSpheres * 4)]; uint[] smat = new uint[Math.Max(1, n.NSpheres)];
-        PtMaterial[] mats = new PtMaterial[n.NMats];
+        Ptrt.Check(Ptrt.pt_scenegen((uint)kind, detail, seed, Width, Height, &n, null, null, null, null, null, null, null));
+        float[] verts = new float[n.n_tris * 9]; uint[] tmat = new uint[n.n_tris];
+        float[] sph = new float[Math.Max(1, n.n_spheres * 4)]; uint[] smat = new uint[Math.Max(1, n.n_spheres)];
+        PtMaterial[] mats = new PtMaterial[n.n_mats];
         fixed (float* v = verts, s = sph) fixed (uint* tm = tmat, sm = smat) fixed (PtMaterial* m = mats)
         {
-            Ptrt.Check(Ptrt.pt_scenegen(kind, detail, seed, Width, Height, &n, v, tm, s, sm, m, &cam, sky));
+            Ptrt.Check(Ptrt.pt_scenegen((uint)kind, detail, seed, Width, Height, &n, v, tm, s, sm, m, &cam, sky));
             if (_scene != null) Ptrt.pt_scene_destroy(_scene);
             void* sc; Ptrt.Check(Ptrt.pt_scene_create(_ctx, &sc), _ctx); _scene = sc;
-            Ptrt.Check(Ptrt.pt_scene_set_triangles(sc, v, tm, n.NTris), _ctx);
-            Ptrt.Check(Ptrt.pt_scene_set_spheres(sc, s, sm, n.NSpheres), _ctx);
-            Ptrt.Check(Ptrt.pt_scene_set_materials(sc, m, n.NMats), _ctx);
+            Ptrt.Check(Ptrt.pt_scene_set_triangles(sc, v, tm, n.n_tris), _ctx);
+            Ptrt.Check(Ptrt.pt_scene_set_spheres(sc, s, sm, n.n_spheres), _ctx);
+            Ptrt.Check(Ptrt.pt_scene_set_materials(sc, m, n.n_mats), _ctx);
             Ptrt.Check(Ptrt.pt_scene_set_camera(sc, &cam), _ctx);
             Ptrt.Check(Ptrt.pt_scene_set_sky(sc, sky), _ctx);
             Ptrt.Check(Ptrt.pt_scene_commit(sc, bvhWidth), _ctx);
         }
-        Params.Mode = (uint)PtMode.PathTrace;
+        Params.mode = (uint)PtMode.PathTrace;
     }
 
     public void Update(float deltaTime) { } // empty in the reference too (Renderer.cs:86-89)
@@ -58,7 +58,7 @@ public unsafe class HipRenderer : IDisposable
     private void ComputeFrame(float delta)
     {
         fixed (PtRenderParams* p = &Params) fixed (PtStats* st = &LastStats)
-            Ptrt.Check(Ptrt.pt_render(_ctx, Params.Mode == (uint)PtMode.PathTrace ? _scene : null, p, st), _ctx);
+            Ptrt.Check(Ptrt.pt_render(_ctx, Params.mode == (uint)PtMode.PathTrace ? _scene : null, p, st), _ctx);
     }
 
     public float[] ReadFramebuffer()

@@ -118,13 +118,13 @@ typedef struct {
     uint64_t paths;
     uint64_t node_visits, tri_tests, sphere_tests; /* only with PT_FLAG_COUNT_VISITS, else 0 */
     uint32_t iterations;    /* wavefront iterations = launches of the extend kernel; the default (fused) kernel advances every
-                               path by up to PTRT_BOUNCES (4) vertices per iteration */
+                               path by up to max_depth / 2 clamped to [4, 8] vertices per iteration (PTRT_BOUNCES overrides) */
     uint32_t extend_launches;
     double gpu_ms;          /* hipEvent start->stop around all kernels of the frame */
     double extend_ms;       /* sum of extend-kernel durations (PT_FLAG_PROFILE_KERNELS); includes shading when fused */
     double shade_ms;        /* sum of shade-kernel durations  (PT_FLAG_PROFILE_KERNELS); ~0 when fused */
     double other_ms;        /* generate / resolve kernels */
-    uint64_t reserved[4];   /* diagnostics: [0] extend kernel in use (1 one ray per lane, 2 lane-packing, 0 unprobed),
+    uint64_t reserved[4];   /* diagnostics: [0] extend kernel in use (1 one ray per lane, 2 lane-packing, 3 pooled, 0 unprobed),
                                [1] iterations that re-packed their queues, [2] path states loaded+stored by the loop
                                (sum over iterations of the paths alive at its start), [3] with PT_FLAG_COUNT_VISITS: wave-level
                                iterations of k_extend's node loop in bits 0-39 (node_visits / (64 * that) = lane utilisation of the
@@ -132,15 +132,16 @@ typedef struct {
 } pt_stats;
 
 typedef struct {
-    uint32_t width;          /* the layout id the scene was committed with: PT_BVH_WIDTH_2, _4 or _4Q */
+    uint32_t width;          /* the layout id the scene was committed with: PT_BVH_WIDTH_2, _4, _4Q or _8Q */
     uint32_t n_nodes;
     uint32_t n_tris;
     uint32_t max_depth;
-    uint64_t node_bytes;     /* n_nodes * 64 (layouts 2 and 4Q) or n_nodes * 128 (layout 4) */
+    uint64_t node_bytes;     /* n_nodes * 64 (layouts 2 and 4Q) or n_nodes * 128 (layouts 4 and 8Q) */
     uint64_t tri_bytes;      /* n_tris * 48 */
     double build_ms;
     float sah_cost;
-    uint32_t reserved;
+    uint32_t stack_need;     /* worst-case traversal-stack depth of this tree (entries); the kernels keep 12 per lane in LDS and
+                                size a global overflow area from this */
 } pt_bvh_info;
 
 /* ---- context: replaces GraphicsDevice.Init (GraphicsDevice.cs:38-43) + Renderer.CreateResources (Renderer.cs:105-196) */
@@ -172,6 +173,10 @@ pt_status pt_render(pt_context *ctx, const pt_scene *scene, const pt_render_para
 pt_status pt_framebuffer_read(pt_context *ctx, float *rgba, uint64_t n_floats);
 pt_status pt_framebuffer_read_rgba8(pt_context *ctx, uint8_t *rgba8, uint64_t n_bytes); /* R8G8B8A8Unorm, Renderer.cs:124 */
 pt_status pt_framebuffer_device_ptr(pt_context *ctx, void **dptr, uint64_t *n_floats);   /* row-major float4 on the device */
+/* What the reference's window shows: its display pass samples the R8G8B8A8Unorm image with a nearest sampler (Renderer.cs:184-185)
+ * and writes it to a B8G8R8A8Srgb swapchain (SwapChain.cs:157-158), i.e. every 8-bit linear value q becomes
+ * round(255 * srgb_oetf(q / 255)). No tone mapping: radiance above 1 clips, as it does in the UNORM image. RGBA order. */
+pt_status pt_framebuffer_read_srgb8(pt_context *ctx, uint8_t *rgba8, uint64_t n_bytes);
 
 /* ---- image-space partition (docs/SPEC.md §6). After pt_render with nranks > 1 the rank's tiles sit
  * tile-major in a device staging buffer; the host gathers them (RCCL via torch.distributed or
@@ -183,9 +188,34 @@ typedef struct {
     uint64_t floats_per_tile; /* tile_size^2 * 4 */
 } pt_tile_layout;
 pt_status pt_tile_layout_query(const pt_render_params *params, pt_tile_layout *out);
-pt_status pt_tiles_device_ptr(pt_context *ctx, void **dptr, uint64_t *n_floats); /* tiles_per_rank*floats_per_tile floats */
+/* tiles_per_rank*floats_per_tile floats. Ownership: the buffer is rewritten by the context's next pt_render, on the context's
+ * own streams — a caller that hands it to an asynchronous collective on another stream must wait for that collective before it
+ * renders again (bench.py does; pt_comm orders the two on one stream). */
+pt_status pt_tiles_device_ptr(pt_context *ctx, void **dptr, uint64_t *n_floats);
 /* gathered = nranks blocks of tiles_per_rank*floats_per_tile floats (device pointer on ctx's device) */
 pt_status pt_assemble_tiles(pt_context *ctx, const pt_render_params *params, const void *gathered_dptr, uint64_t n_floats);
+
+/* ---- several GPUs of one node behind one call (docs/SPEC.md §6). The reference is single-device (GraphicsDevice.cs:176-183) and its
+ * host is one process (Program.cs:3-7), so a C# caller cannot use a process-per-GPU launcher: a pt_comm holds one pt_context per
+ * rank inside the calling process. Ranks on distinct devices exchange their tiles with ONE ncclGather per frame over an RCCL
+ * communicator made by ncclCommInitAll (librccl.so.1 is loaded on first use; libptrt does not link it). Ranks that share one
+ * context ("virtual ranks": rehearsal of the partition on a single GPU) are rendered one after the other and staged by device
+ * copies. A rank's tile buffer (pt_tiles_device_ptr) belongs to the library between pt_render and the end of the exchange. */
+typedef struct pt_comm pt_comm;
+enum { PT_COMM_FORCE_RCCL = 1u }; /* pt_comm_create flags: use the RCCL path even for a single rank (plumbing check on one GPU) */
+/* ctxs[i] renders rank i of n_ranks; the assembled frame lands in ctxs[root] (pt_framebuffer_read*). Either every rank has its own
+ * context on its own device, or all ranks share one context. */
+pt_status pt_comm_create(pt_context *const *ctxs, uint32_t n_ranks, uint32_t root, uint32_t flags, pt_comm **out);
+void pt_comm_destroy(pt_comm *comm);
+/* One frame: rank i renders its tiles of `params` (rank / nranks are filled in) on scenes[i] — the same scene committed on every
+ * context — concurrently (one host thread per context), then the tiles are gathered to the root and assembled there.
+ * stats: n_ranks entries or NULL. Synchronous, like pt_render. */
+pt_status pt_comm_render(pt_comm *comm, const pt_scene *const *scenes, const pt_render_params *params, pt_stats *stats);
+/* The two halves of the exchange for callers that drive pt_render themselves (rank = the rank just rendered on its context):
+ * pt_comm_stage_tiles copies that rank's tile block to where the exchange wants it; pt_comm_assemble runs the exchange (if any
+ * rank lives on another device) and un-tiles the gathered blocks into the root's framebuffer. */
+pt_status pt_comm_stage_tiles(pt_comm *comm, uint32_t rank);
+pt_status pt_comm_assemble(pt_comm *comm, const pt_render_params *params);
 
 /* ---- deterministic synthetic scenes (C1..C5); host only, no device needed.
  * Two-call pattern: pass NULL arrays to get counts, then buffers of those sizes. */

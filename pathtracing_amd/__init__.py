@@ -5,8 +5,8 @@ The product is `libptrt.so` (HIP, gfx950; C ABI in include/ptrt.h). This package
 if it is missing; nothing here computes pixels on the CPU.
 """
 from . import _native as native  # noqa: F401  (raises ImportError if libptrt.so is not built)
-from .host import (App, Renderer, Window, SceneData, PtException, make_scene, make_params, tile_layout,  # noqa: F401
+from .host import (App, Comm, Renderer, Window, SceneData, PtException, make_scene, make_params, tile_layout,  # noqa: F401
                    MATERIAL_DTYPE)
 
-__all__ = ["App", "Renderer", "Window", "SceneData", "PtException", "make_scene", "make_params", "tile_layout",
+__all__ = ["App", "Comm", "Renderer", "Window", "SceneData", "PtException", "make_scene", "make_params", "tile_layout",
            "MATERIAL_DTYPE", "native"]

@@ -38,6 +38,7 @@ PT_FLAG_SPLIT_KERNELS = 64
 PT_FLAG_EXTEND_POOL = 128
 PT_SCENE_CORNELL, PT_SCENE_CORNELL_GLASS, PT_SCENE_TRIANGLE_SOUP, PT_SCENE_CORNELL_TESS = 0, 1, 2, 3
 PT_BVH_WIDTH_2, PT_BVH_WIDTH_4, PT_BVH_WIDTH_4Q, PT_BVH_WIDTH_8Q, PT_BVH_BUILD_LBVH = 2, 4, 68, 72, 0x100
+PT_COMM_FORCE_RCCL = 1
 
 
 class pt_device_desc(C.Structure):
@@ -71,7 +72,7 @@ class pt_stats(C.Structure):
 class pt_bvh_info(C.Structure):
     _fields_ = [("width", C.c_uint32), ("n_nodes", C.c_uint32), ("n_tris", C.c_uint32), ("max_depth", C.c_uint32),
                 ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64), ("build_ms", C.c_double),
-                ("sah_cost", C.c_float), ("reserved", C.c_uint32)]
+                ("sah_cost", C.c_float), ("stack_need", C.c_uint32)]
 
 
 class pt_tile_layout(C.Structure):
@@ -107,10 +108,16 @@ SYMBOLS = {
     "pt_render": (_st, [_vp, _vp, _P(pt_render_params), _P(pt_stats)]),
     "pt_framebuffer_read": (_st, [_vp, _vp, _u64]),
     "pt_framebuffer_read_rgba8": (_st, [_vp, _vp, _u64]),
+    "pt_framebuffer_read_srgb8": (_st, [_vp, _vp, _u64]),
     "pt_framebuffer_device_ptr": (_st, [_vp, _P(_vp), _P(_u64)]),
     "pt_tile_layout_query": (_st, [_P(pt_render_params), _P(pt_tile_layout)]),
     "pt_tiles_device_ptr": (_st, [_vp, _P(_vp), _P(_u64)]),
     "pt_assemble_tiles": (_st, [_vp, _P(pt_render_params), _vp, _u64]),
+    "pt_comm_create": (_st, [_P(_vp), _u32, _u32, _u32, _P(_vp)]),
+    "pt_comm_destroy": (None, [_vp]),
+    "pt_comm_render": (_st, [_vp, _P(_vp), _P(pt_render_params), _P(pt_stats)]),
+    "pt_comm_stage_tiles": (_st, [_vp, _u32]),
+    "pt_comm_assemble": (_st, [_vp, _P(pt_render_params)]),
     "pt_scenegen": (_st, [_u32, _u32, _u32, _u32, _u32, _P(pt_scene_counts), _vp, _vp, _vp, _vp, _vp, _P(pt_camera), _vp]),
 }
 

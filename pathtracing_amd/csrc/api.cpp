@@ -105,7 +105,7 @@ struct pt_scene {
     uint64_t node_bytes() const { return quantised() ? packed_nodes.size() : bvh.slots.size() * sizeof(BvhSlot); }
     DevBuf<float4> d_nodes, d_tris, d_spheres, d_mats;
     bool has_specular = false;
-    uint32_t ext_choice = 0;             // extend kernel picked by the probe of an earlier frame (0 = none yet, 1 = simple, 2 = packed)
+    mutable uint32_t ext_choice = 0;     // cache, not scene content: the extend kernel an earlier frame's probe picked (0 = none yet, ExtendKernel otherwise)
     DevBuf<uint32_t> d_sph_mat;
     DeviceScene ds{};
 };
@@ -157,6 +157,12 @@ hipEvent_t pool_event(pt_context *c, size_t i)
 }
 
 } // namespace
+
+namespace ptrt {
+int context_device(const pt_context *c) { return c->device; }
+hipStream_t context_stream(const pt_context *c) { return c->stream; }
+void context_set_error(pt_context *c, const char *msg) { g_err = msg; if (c) c->err = msg; }
+} // namespace ptrt
 
 extern "C" {
 
@@ -214,6 +220,7 @@ void pt_context_destroy(pt_context *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (auto &gs : c->group_stream) if (gs) (void)hipStreamSynchronize(gs); // nothing may still run on the buffers released below
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->ray_o.release(); c->ray_d.release(); c->thr.release(); c->acc.release(); c->tiles.release(); c->fb.release(); c->hit.release();
     c->sd.release(); c->q_ext0.release(); c->q_ext1.release(); c->counters.release(); c->fb8.release(); c->stack_ovf.release();
@@ -401,7 +408,7 @@ pt_status pt_scene_bvh_info(const pt_scene *s, pt_bvh_info *o)
     o->node_bytes = s->node_bytes();
     o->tri_bytes = (uint64_t)s->bvh.tris.size() * sizeof(BvhTri);
     o->build_ms = s->bvh.build_ms; o->sah_cost = s->bvh.sah_cost;
-    o->reserved = s->bvh.stack_need;
+    o->stack_need = s->bvh.stack_need;
     return PT_OK;
 }
 
@@ -434,7 +441,21 @@ static pt_status ensure_frame(pt_context *c, uint32_t w, uint32_t h)
     return PT_OK;
 }
 
+static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_params *p, pt_stats *stats);
+
 pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p, pt_stats *stats)
+{
+    const pt_status st = render_frame(c, s, p, stats);
+    if (st != PT_OK && c) { // an error exit may leave kernels in flight on the loop streams: nothing of this frame survives the call
+        (void)hipSetDevice(c->device);
+        for (auto &gs : c->group_stream) if (gs) (void)hipStreamSynchronize(gs);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        c->acc_spp = 0; c->fb_valid = false;
+    }
+    return st;
+}
+
+static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_params *p, pt_stats *stats)
 {
     if (!c || !p) return fail(c, PT_ERR_INVALID_ARGUMENT, "pt_render: NULL argument");
     pt_tile_layout lay;
@@ -556,8 +577,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
     // of group 0 runs the one-ray-per-lane kernel, iteration 3 the lane-packing one (bit-identical results), each
     // bracketed by events; the faster per ray wins for the rest of the frame and for later frames. Deep incoherent
     // traversals (1M-triangle soup) gain ~1.5x from packing, shallow ones (walls of a box) lose ~8 %, and nothing static tells them apart.
-    pt_scene *scene_mut = const_cast<pt_scene *>(s);
-    uint32_t ext_choice = forced_choice ? forced_choice : scene_mut->ext_choice; // 0 = still probing, 1 = simple, 2 = packed
+    uint32_t ext_choice = forced_choice ? forced_choice : s->ext_choice; // 0 = still probing, else ExtendKernel
     uint64_t probe_n[2] = { 0, 0 }, slot_launches = 0;
     const bool trace = profile && getenv("PTRT_TRACE") != nullptr; // developer aid: per-iteration table on stderr
     std::vector<uint64_t> trace_alive, trace_rays;
@@ -630,7 +650,7 @@ pt_status pt_render(pt_context *c, const pt_scene *s, const pt_render_params *p,
                     HIP_TRY(c, hipEventElapsedTime(&ms_packed, c->ev_probe[2], c->ev_probe[3]));
                     const double r_simple = probe_n[0] / std::max((double)ms_simple, 1e-6), r_packed = probe_n[1] / std::max((double)ms_packed, 1e-6);
                     ext_choice = (probe_n[0] && probe_n[1] && r_packed > 1.10 * r_simple) ? 2u : 1u;
-                    scene_mut->ext_choice = ext_choice;
+                    s->ext_choice = ext_choice;
                 }
             }
         }
@@ -717,6 +737,22 @@ pt_status pt_framebuffer_read_rgba8(pt_context *c, uint8_t *rgba8, uint64_t n_by
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(rgba8, c->fb8.p, need, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+pt_status pt_framebuffer_read_srgb8(pt_context *c, uint8_t *rgba8, uint64_t n_bytes)
+{
+    // display transform of the reference (SwapChain.cs:157-158 B8G8R8A8Srgb target, nearest-sampled UNORM8 source): a function of
+    // the 8-bit value, so it is a 256-entry table over the UNORM8 read-back; alpha is linear in sRGB formats
+    pt_status st = pt_framebuffer_read_rgba8(c, rgba8, n_bytes);
+    if (st != PT_OK) return st;
+    uint8_t lut[256];
+    for (int q = 0; q < 256; ++q) {
+        const double l = q / 255.0, e = l <= 0.0031308 ? 12.92 * l : 1.055 * std::pow(l, 1.0 / 2.4) - 0.055;
+        lut[q] = (uint8_t)std::floor(255.0 * e + 0.5);
+    }
+    const uint64_t n = (uint64_t)c->fb_w * c->fb_h * 4;
+    for (uint64_t i = 0; i < n; ++i) if ((i & 3u) != 3u) rgba8[i] = lut[rgba8[i]];
     return PT_OK;
 }
 

@@ -125,6 +125,11 @@ hipError_t launch_assemble(hipStream_t s, const float4 *gathered, uint32_t nrank
                            uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, float inv_spp,
                            float4 *fb, uint32_t *fb8);
 
+// api.cpp: what comm.cpp needs to know about a context
+int context_device(const pt_context *c);
+hipStream_t context_stream(const pt_context *c);
+void context_set_error(pt_context *c, const char *msg); // c == NULL: the calling thread's last error
+
 // lbvh.hip: Morton sort + Karras hierarchy + refit on the device; returns the binary tree on the host
 struct BinaryBvh;
 hipError_t build_lbvh_device(hipStream_t s, const float *verts9, uint32_t n_tris, BinaryBvh &out);

@@ -200,9 +200,18 @@ class Renderer:
         _check(N.lib.pt_framebuffer_read_rgba8(self._ctx, _ptr(out), out.size), self._ctx)
         return out
 
-    def SaveImage(self, path):
+    def ReadFramebufferSRGB8(self):
+        """The frame as the reference's window would show it (UNORM8 image -> B8G8R8A8Srgb swapchain, SwapChain.cs:157-158)."""
+        w, h = self.Params.width, self.Params.height
+        out = np.empty((h, w, 4), np.uint8)
+        _check(N.lib.pt_framebuffer_read_srgb8(self._ctx, _ptr(out), out.size), self._ctx)
+        return out
+
+    def SaveImage(self, path, srgb=False):
         """Image output — what replaces the reference's window (display path Renderer.cs:1042-1121).
-        `.ppm`: 8-bit, the clamp-and-round R8G8B8A8Unorm image of Renderer.cs:124; `.pfm`: linear float radiance, bottom-up rows."""
+        `.ppm`: 8-bit, the clamp-and-round R8G8B8A8Unorm image of Renderer.cs:124 — or, with srgb=True, what the reference's
+        sRGB swapchain shows of it (SwapChain.cs:157-158; no tone mapping, values above 1 clip); `.pfm`: linear float radiance,
+        bottom-up rows."""
         w, h = self.Params.width, self.Params.height
         if path.lower().endswith(".pfm"):
             rgb = np.ascontiguousarray(self.ReadFramebuffer()[::-1, :, :3], "<f4")
@@ -210,7 +219,7 @@ class Renderer:
                 f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
                 f.write(rgb.tobytes())
         else:
-            rgb = np.ascontiguousarray(self.ReadFramebufferRGBA8()[..., :3])
+            rgb = np.ascontiguousarray((self.ReadFramebufferSRGB8() if srgb else self.ReadFramebufferRGBA8())[..., :3])
             with open(path, "wb") as f:
                 f.write(b"P6\n%d %d\n255\n" % (w, h))
                 f.write(rgb.tobytes())
@@ -247,6 +256,46 @@ class Renderer:
             self.Dispose()
         except Exception:
             pass
+
+
+class Comm:
+    """Several ranks of one frame behind one call (include/ptrt.h pt_comm): one Renderer per rank on its own GPU (tiles exchanged by
+    one ncclGather per frame inside libptrt), or the same Renderer for every rank (virtual ranks rendered one after the other: the
+    partition rehearsed on a single GPU). Every renderer must hold the same scene. The frame lands in renderers[root]."""
+
+    def __init__(self, renderers, root=0, flags=0):
+        self.Renderers = list(renderers)
+        self.Root = root
+        self._comm = C.c_void_p()
+        ctxs = (C.c_void_p * len(self.Renderers))(*[r._ctx for r in self.Renderers])
+        _check(N.lib.pt_comm_create(ctxs, len(self.Renderers), root, flags, C.byref(self._comm)))
+
+    def Render(self, params):
+        """One frame of `params` over all ranks; returns the per-rank pt_stats."""
+        n = len(self.Renderers)
+        scenes = (C.c_void_p * n)(*[r._scene for r in self.Renderers])
+        stats = (N.pt_stats * n)()
+        _check(N.lib.pt_comm_render(self._comm, scenes, C.byref(params), stats), self.Renderers[self.Root]._ctx)
+        self.Renderers[self.Root].Params = params
+        return list(stats)
+
+    def StageTiles(self, rank):
+        _check(N.lib.pt_comm_stage_tiles(self._comm, rank), self.Renderers[self.Root]._ctx)
+
+    def Assemble(self, params):
+        _check(N.lib.pt_comm_assemble(self._comm, C.byref(params)), self.Renderers[self.Root]._ctx)
+        self.Renderers[self.Root].Params = params
+
+    def Dispose(self):
+        if self._comm:
+            N.lib.pt_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.Dispose()
 
 
 class App:

@@ -1,0 +1,161 @@
+"""The C# P/Invoke layer (host/csharp/PtrtNative.cs) cannot be compiled in this image (no dotnet), so nothing but this test keeps
+it in step with include/ptrt.h: both files are parsed and compared — struct field order, types and fixed-array sizes, every
+[DllImport] signature against the C prototype, enum values — and the comparison is shown to fail when a field is swapped, a
+function is missing or an argument type is wrong. (The reference's project: RayTracing.csproj:5,8 — net8.0, AllowUnsafeBlocks.)"""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ptrt.h")
+CSHARP = os.path.join(ROOT, "host", "csharp", "PtrtNative.cs")
+
+C_TO_CS = {"uint32_t": "uint", "int32_t": "int", "uint64_t": "ulong", "uint8_t": "byte", "float": "float", "double": "double", "void": "void",
+           "char": "sbyte", "pt_status": "PtStatus", "pt_context": "void", "pt_scene": "void", "pt_comm": "void"}
+
+
+def camel(name):  # pt_render_params -> PtRenderParams
+    return "".join(w.capitalize() for w in name.split("_"))
+
+
+def strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", text)
+
+
+def parse_header(text):
+    text = strip_comments(text)
+    structs, funcs, enums = {}, {}, {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r"(const\s+)?(\w+)\s+(.*)$", decl, flags=re.S)
+            ctype, rest = m.group(2), m.group(3)
+            for item in rest.split(","):
+                item = item.strip()
+                ptr = item.count("*")
+                item = item.replace("*", "").strip()
+                am = re.match(r"(\w+)\s*\[(\d+)\]$", item)
+                fname, n = (am.group(1), int(am.group(2))) if am else (item, 0)
+                fields.append((fname, C_TO_CS.get(ctype, camel(ctype)) + "*" * ptr, n))
+        structs[camel(name)] = fields
+    for body in re.findall(r"enum\s*\{(.*?)\}\s*;", text, flags=re.S):
+        nxt = 0
+        for item in body.split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                k, v = [x.strip() for x in item.split("=")]
+                nxt = int(v.rstrip("uU"), 0)
+            else:
+                k = item
+            enums[k] = nxt
+            nxt += 1
+    protos = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", " ", text, flags=re.S)
+    for ret, name, args in re.findall(r"((?:const\s+)?\w+\s*\**)\s*\b(pt_\w+)\s*\(([^()]*)\)\s*;", protos):
+        funcs[name] = (c_type(ret), [c_type(a, True) for a in args.split(",") if a.strip() and a.strip() != "void"])
+    return structs, funcs, enums
+
+
+def c_type(decl, is_param=False):
+    """'const pt_render_params *params' -> 'PtRenderParams*'; 'pt_context *const *ctxs' -> 'void**'; 'const float rgb[3]' -> 'float*'."""
+    d = decl.replace("const", " ").strip()
+    ptr = d.count("*") + d.count("[")
+    d = re.sub(r"\[\d*\]", " ", d).replace("*", " ")
+    words = d.split()
+    base = words[0]
+    return C_TO_CS.get(base, camel(base)) + "*" * ptr
+
+
+def parse_csharp(text):
+    text = strip_comments(text)
+    structs, funcs, enums = {}, {}, {}
+    for name, body in re.findall(r"struct\s+(\w+)\s*\{(.*?)\}", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r"public\s+(fixed\s+)?([\w*]+)\s+(\w+)(?:\[(\d+)\])?$", decl)
+            assert m, f"unparsed C# field: {decl!r}"
+            fields.append((m.group(3), m.group(2), int(m.group(4)) if m.group(4) else 0))
+        structs[name] = fields
+    for ret, name, args in re.findall(r"\[DllImport\(Lib\)\]\s*public\s+static\s+extern\s+([\w*]+)\s+(\w+)\s*\(([^()]*)\)\s*;", text, flags=re.S):
+        funcs[name] = (ret, [a.split()[0] for a in args.split(",") if a.strip()])
+    for name, body in re.findall(r"enum\s+(\w+)\s*:\s*\w+\s*\{(.*?)\}", text, flags=re.S):
+        nxt, vals = 0, {}
+        for item in body.split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                k, v = [x.strip() for x in item.split("=")]
+                nxt = int(v, 0)
+            else:
+                k = item
+            vals[k] = nxt
+            nxt += 1
+        enums[name] = vals
+    return structs, funcs, enums
+
+
+ENUM_PREFIX = {"PtStatus": ("PT_ERR_", {"PT_OK": "Ok"}), "PtMode": ("PT_", {}), "PtMaterialKind": ("PT_", {}), "PtSceneKind": ("PT_SCENE_", {}),
+               "PtFlags": ("PT_FLAG_", {})}
+
+
+def compare(header_text, cs_text):
+    """Returns the list of mismatches between the header and the C# binding (empty = in step)."""
+    hs, hf, he = parse_header(header_text)
+    cs, cf, ce = parse_csharp(cs_text)
+    errs = []
+    for name, fields in hs.items():
+        if name not in cs:
+            errs.append(f"struct {name} missing in C#")
+        elif fields != cs[name]:
+            errs.append(f"struct {name}: header {fields} != C# {cs[name]}")
+    for name, sig in hf.items():
+        if name not in cf:
+            errs.append(f"function {name} not imported in C#")
+        elif sig != cf[name]:
+            errs.append(f"function {name}: header {sig} != C# {cf[name]}")
+    for name in cf:
+        if name not in hf:
+            errs.append(f"C# imports {name}, which the header does not declare")
+    for ename, (prefix, special) in ENUM_PREFIX.items():
+        for k, v in ce[ename].items():
+            hk = next((h for h, c in special.items() if c == k), None) or prefix + re.sub(r"(?<!^)(?=[A-Z])", "_", k).upper()
+            if he.get(hk) != v:
+                errs.append(f"enum {ename}.{k} = {v}, header {hk} = {he.get(hk)}")
+    return errs
+
+
+def test_csharp_binding_matches_the_header():
+    errs = compare(open(HEADER).read(), open(CSHARP).read())
+    assert not errs, "\n".join(errs)
+
+
+def test_every_header_struct_and_function_was_seen():
+    hs, hf, he = parse_header(open(HEADER).read())
+    assert set(hs) == {"PtDeviceDesc", "PtMaterial", "PtCamera", "PtRenderParams", "PtStats", "PtBvhInfo", "PtTileLayout", "PtSceneCounts"}
+    import pathtracing_amd._native as N
+    assert set(hf) == set(N.SYMBOLS), set(hf) ^ set(N.SYMBOLS)  # the parser sees exactly the entry points the ctypes binding declares
+    assert he["PT_FLAG_EXTEND_POOL"] == 128 and he["PT_ERR_INTERNAL"] == 7 and he["PT_BVH_WIDTH_8Q"] == 72
+
+
+def test_the_guard_fails_when_the_binding_drifts():
+    h, c = open(HEADER).read(), open(CSHARP).read()
+    swapped = c.replace("public uint rank; public uint nranks;", "public uint nranks; public uint rank;")
+    assert swapped != c and any("PtRenderParams" in e for e in compare(h, swapped))
+    retyped = c.replace("public double build_ms;", "public float build_ms;")
+    assert retyped != c and any("PtBvhInfo" in e for e in compare(h, retyped))
+    resized = c.replace("public fixed float up[3];", "public fixed float up[4];")
+    assert resized != c and any("PtCamera" in e for e in compare(h, resized))
+    dropped = re.sub(r"\[DllImport\(Lib\)\] public static extern PtStatus pt_comm_assemble[^\n]*\n", "", c)
+    assert dropped != c and any("pt_comm_assemble" in e for e in compare(h, dropped))
+    wrong_arg = c.replace("pt_scene_commit(void* s, uint bvh_width)", "pt_scene_commit(void* s, ulong bvh_width)")
+    assert wrong_arg != c and any("pt_scene_commit" in e for e in compare(h, wrong_arg))
+    wrong_enum = c.replace("ExtendPool = 128", "ExtendPool = 256")
+    assert wrong_enum != c and any("ExtendPool" in e for e in compare(h, wrong_enum))

@@ -205,8 +205,10 @@ def test_gpu_lbvh_builder(P, pto, renderer, layout):
 
 
 def test_rank_partition_is_image_invariant(P, pto, renderer):
-    """SPEC §6: the picture must not depend on the number of ranks. Two 'ranks' rendered one after the other on this GPU,
-    concatenated as a gather would, assembled by pt_assemble_tiles == the single-rank frame, bit for bit."""
+    """SPEC §6: the picture must not depend on the number of ranks. R 'virtual ranks' rendered one after the other on this GPU and
+    assembled through the library's own exchange entry points (pt_comm_*) == the single-rank frame, bit for bit — once with
+    pt_comm_render, once with the caller driving pt_render + pt_comm_stage_tiles + pt_comm_assemble, and once by hand through
+    pt_tiles_device_ptr / pt_assemble_tiles (what a process-per-GPU host does around its own collective)."""
     import torch
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 1, 200, 131)
     renderer.SetScene(sd, 4)
@@ -214,6 +216,18 @@ def test_rank_partition_is_image_invariant(P, pto, renderer):
     one = renderer.Render(0.0)
     want = renderer.ReadFramebuffer()
     for nranks in (2, 3, 5):
+        with P.Comm([renderer] * nranks, root=nranks - 1) as comm:
+            stats = comm.Render(P.make_params(200, 131, spp=3, max_depth=6))
+            assert sum(s.rays for s in stats) == one.rays and sum(s.paths for s in stats) == one.paths
+            assert np.array_equal(renderer.ReadFramebuffer(), want), nranks
+            for rank in range(nranks):  # the same, driven from outside
+                renderer.Params = P.make_params(200, 131, spp=3, max_depth=6, rank=rank, nranks=nranks)
+                renderer.Render(0.0)
+                comm.StageTiles(rank)
+            comm.Assemble(P.make_params(200, 131, spp=3, max_depth=6))
+            assert np.array_equal(renderer.ReadFramebuffer(), want), nranks
+            with pytest.raises(P.PtException, match="not staged"):
+                comm.Assemble(P.make_params(200, 131, spp=3, max_depth=6))
         blocks, rays = [], 0
         for rank in range(nranks):
             renderer.Params = P.make_params(200, 131, spp=3, max_depth=6, rank=rank, nranks=nranks)
@@ -225,6 +239,24 @@ def test_rank_partition_is_image_invariant(P, pto, renderer):
         renderer.AssembleTiles(gathered.data_ptr(), gathered.numel())
         assert rays == one.rays
         assert np.array_equal(renderer.ReadFramebuffer(), want), nranks
+
+
+def test_comm_rccl_path_on_one_gpu(P, pto, renderer):
+    """pt_comm with PT_COMM_FORCE_RCCL and one rank: librccl is dlopen-ed, ncclCommInitAll makes a one-rank communicator and the
+    frame goes through ncclGather + un-tiling — the code path of the multi-GPU exchange, as far as one GPU can take it."""
+    N = P.native
+    sd = P.make_scene(N.PT_SCENE_CORNELL_TESS, 20000, 3, 300, 170)
+    renderer.SetScene(sd, 0)
+    p = P.make_params(300, 170, spp=4, max_depth=6, streams=2)
+    renderer.Params = p
+    one = renderer.Render(0.0)
+    want = renderer.ReadFramebuffer()
+    with P.Comm([renderer], flags=N.PT_COMM_FORCE_RCCL) as comm:
+        for _ in range(2):
+            stats = comm.Render(p)
+            assert stats[0].rays == one.rays and np.array_equal(renderer.ReadFramebuffer(), want)
+    with pytest.raises(P.PtException):
+        P.Comm([renderer], root=1)
 
 
 @pytest.mark.parametrize("streams", [2, 4, 7, 40])
@@ -412,6 +444,15 @@ def test_image_output(P, pto, renderer, tmp_path):
     of, ob = pto.reference_sphere(97, 41)
     raw = open(tmp_path / "f.ppm", "rb").read()
     assert raw.startswith(b"P6\n97 41\n255\n") and np.array_equal(np.frombuffer(raw[len(b"P6\n97 41\n255\n"):], np.uint8).reshape(41, 97, 3), ob[..., :3])
+    # what the reference's window shows: the UNORM8 image through its sRGB swapchain (SwapChain.cs:157-158), alpha linear
+    s8 = renderer.ReadFramebufferSRGB8()
+    lin = ob.astype(np.float64) / 255.0
+    enc = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * lin ** (1 / 2.4) - 0.055)
+    want = np.floor(255.0 * enc + 0.5).astype(np.uint8)
+    assert np.array_equal(s8[..., :3], want[..., :3]) and np.array_equal(s8[..., 3], ob[..., 3])
+    renderer.SaveImage(str(tmp_path / "s.ppm"), srgb=True)
+    raw = open(tmp_path / "s.ppm", "rb").read()
+    assert np.array_equal(np.frombuffer(raw[len(b"P6\n97 41\n255\n"):], np.uint8).reshape(41, 97, 3), want[..., :3])
     raw = open(tmp_path / "f.pfm", "rb").read()
     hdr = b"PF\n97 41\n-1.0\n"
     assert raw.startswith(hdr) and np.array_equal(np.frombuffer(raw[len(hdr):], "<f4").reshape(41, 97, 3)[::-1], of[..., :3])
