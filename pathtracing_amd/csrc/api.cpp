@@ -6,6 +6,7 @@
 #include "bvh_build.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -45,6 +46,7 @@ template <typename T> struct DevBuf {
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void adopt(void *q, size_t count) { release(); p = (T *)q; n = count; } // take over a hipMalloc-ed array
 };
 
 } // namespace
@@ -100,9 +102,12 @@ struct pt_scene {
     BvhBlob bvh;
     uint32_t layout = 0;                 // PT_BVH_WIDTH_* the scene was committed with
     std::vector<uint8_t> packed_nodes;   // layouts PT_BVH_WIDTH_4Q / _8Q: the 64- / 128-byte nodes that are uploaded / read back
+    bool device_packed = false;          // the blob was packed on the device (lbvh.hip build_lbvh_blob4q_device): the host copies below
+    mutable bool host_mirror = true;     // (packed_nodes, bvh.tris) are fetched from the device the first time pt_scene_bvh_read wants them
     bool quantised() const { return layout == PT_BVH_WIDTH_4Q || layout == PT_BVH_WIDTH_8Q; }
     const void *node_data() const { return quantised() ? (const void *)packed_nodes.data() : (const void *)bvh.slots.data(); }
-    uint64_t node_bytes() const { return quantised() ? packed_nodes.size() : bvh.slots.size() * sizeof(BvhSlot); }
+    uint64_t node_bytes() const { return device_packed ? (uint64_t)bvh.n_nodes * 64u : quantised() ? packed_nodes.size() : bvh.slots.size() * sizeof(BvhSlot); }
+    uint64_t n_blob_tris() const { return device_packed ? tri_mat.size() : bvh.tris.size(); }
     DevBuf<float4> d_nodes, d_tris, d_spheres, d_mats;
     bool has_specular = false;
     mutable uint32_t ext_choice = 0;     // cache, not scene content: the extend kernel an earlier frame's probe picked (0 = none yet, ExtendKernel otherwise)
@@ -342,21 +347,41 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     for (uint32_t i = 0; i < ns; ++i) if (s->sph_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "sphere %u: material id %u >= %u", i, s->sph_mat[i], nm);
 
     const uint32_t fan = bvh_width == PT_BVH_WIDTH_2 ? 2u : bvh_width == PT_BVH_WIDTH_8Q ? 8u : 4u;
-    if (lbvh && nt >= 2) {
+    static const bool timing = getenv("PTRT_TIMING") != nullptr; // developer aid: where a commit's time goes, on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t_phase = now();
+    auto lap = [&](const char *what) { if (timing) fprintf(stderr, "ptrt commit: %-28s %8.2f ms\n", what, ms_since(t_phase)); t_phase = now(); };
+    s->device_packed = false; s->host_mirror = true;
+    if (lbvh && nt >= 2 && bvh_width == PT_BVH_WIDTH_4Q) {
+        // the default layout is also packed on the device: nodes and triangle records are born in device memory
+        HIP_TRY(c, hipSetDevice(c->device));
+        DeviceBlob4Q db;
+        HIP_TRY(c, build_lbvh_blob4q_device(c->stream, s->verts.data(), s->tri_mat.data(), nt, db));
+        s->d_nodes.adopt(db.nodes, (size_t)db.n_nodes * 4);
+        s->d_tris.adopt(db.tris, (size_t)nt * 4);
+        s->bvh = BvhBlob{};
+        s->bvh.width = 4; s->bvh.n_nodes = db.n_nodes; s->bvh.max_depth = db.max_depth; s->bvh.stack_need = db.stack_need;
+        s->bvh.sah_cost = db.sah_cost; s->bvh.build_ms = db.device_ms;
+        s->device_packed = true; s->host_mirror = false;
+    } else if (lbvh && nt >= 2) {
         HIP_TRY(c, hipSetDevice(c->device));
         BinaryBvh bt;
         HIP_TRY(c, build_lbvh_device(c->stream, s->verts.data(), nt, bt));
         build_bvh_from_binary(bt, s->verts.data(), s->tri_mat.data(), nt, fan, s->bvh);
     } else build_bvh(s->verts.data(), s->tri_mat.data(), nt, fan, s->bvh);
+    lap("hierarchy + blob");
     if (s->bvh.max_depth > 90) return fail(c, PT_ERR_INTERNAL, "BVH depth %u exceeds the supported 90", s->bvh.max_depth);
     s->layout = bvh_width;
     s->packed_nodes.clear();
-    if (bvh_width == PT_BVH_WIDTH_4Q) quantize_bvh4(s->bvh, s->packed_nodes);
+    if (bvh_width == PT_BVH_WIDTH_4Q && !s->device_packed) quantize_bvh4(s->bvh, s->packed_nodes);
     if (bvh_width == PT_BVH_WIDTH_8Q) quantize_bvh8(s->bvh, s->packed_nodes);
+    lap("quantise");
     if (!c) { s->committed = true; return PT_OK; } // detached scene: host-side blob only
 
     HIP_TRY(c, hipSetDevice(c->device));
     static_assert(sizeof(BvhSlot) == 32 && sizeof(BvhTri) == 48 && sizeof(pt_material) == 48, "blob layout");
+    if (!s->device_packed) {
     HIP_TRY(c, s->d_nodes.ensure((size_t)(s->node_bytes() / 16)));
     HIP_TRY(c, s->d_tris.ensure(s->bvh.tris.size() * 4));
     {   // Device triangle record = one 64-byte line: the blob's three rows (docs/SPEC.md §4.1) + a shading row. A 48-byte
@@ -373,17 +398,21 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
             rec[i * 16 + 12] = cx * inv; rec[i * 16 + 13] = cy * inv; rec[i * 16 + 14] = cz * inv;
             std::memcpy(&rec[i * 16 + 15], &t.mat, 4);
         }
+        lap("triangle records");
         if (!rec.empty()) HIP_TRY(c, hipMemcpy(s->d_tris.p, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
+        lap("upload triangles");
+    }
+    if (s->node_bytes()) HIP_TRY(c, hipMemcpy(s->d_nodes.p, s->node_data(), s->node_bytes(), hipMemcpyHostToDevice));
     }
     HIP_TRY(c, s->d_spheres.ensure(ns));
     HIP_TRY(c, s->d_sph_mat.ensure(ns));
     HIP_TRY(c, s->d_mats.ensure((size_t)nm * 3));
-    if (s->node_bytes()) HIP_TRY(c, hipMemcpy(s->d_nodes.p, s->node_data(), s->node_bytes(), hipMemcpyHostToDevice));
     if (ns) {
         HIP_TRY(c, hipMemcpy(s->d_spheres.p, s->spheres.data(), (size_t)ns * 16, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(s->d_sph_mat.p, s->sph_mat.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
     }
     if (nm) HIP_TRY(c, hipMemcpy(s->d_mats.p, s->mats.data(), (size_t)nm * sizeof(pt_material), hipMemcpyHostToDevice));
+    lap("upload nodes + rest");
 
     DeviceScene &d = s->ds;
     d.nodes = s->d_nodes.p; d.tris = s->d_tris.p; d.spheres = s->d_spheres.p; d.sph_mat = s->d_sph_mat.p; d.mats = s->d_mats.p;
@@ -403,10 +432,10 @@ pt_status pt_scene_bvh_info(const pt_scene *s, pt_bvh_info *o)
     if (!s || !o) return fail(s ? s->ctx : nullptr, PT_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!s->committed) return fail(s->ctx, PT_ERR_NOT_COMMITTED, "scene not committed");
     std::memset(o, 0, sizeof *o);
-    o->width = s->layout; o->n_nodes = s->bvh.n_nodes; o->n_tris = (uint32_t)s->bvh.tris.size();
+    o->width = s->layout; o->n_nodes = s->bvh.n_nodes; o->n_tris = (uint32_t)s->n_blob_tris();
     o->max_depth = s->bvh.max_depth;
     o->node_bytes = s->node_bytes();
-    o->tri_bytes = (uint64_t)s->bvh.tris.size() * sizeof(BvhTri);
+    o->tri_bytes = s->n_blob_tris() * sizeof(BvhTri);
     o->build_ms = s->bvh.build_ms; o->sah_cost = s->bvh.sah_cost;
     o->stack_need = s->bvh.stack_need;
     return PT_OK;
@@ -416,6 +445,18 @@ pt_status pt_scene_bvh_read(const pt_scene *s, void *nodes, uint64_t node_bytes,
 {
     if (!s) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "scene is NULL");
     if (!s->committed) return fail(s->ctx, PT_ERR_NOT_COMMITTED, "scene not committed");
+    if (!s->host_mirror) { // packed on the device: fetch the blob now (nodes as they are, triangles = rows 0-2 of the 64-byte records)
+        pt_scene *m = const_cast<pt_scene *>(s); // fills the host copies the scene owns; device data and results are untouched
+        pt_context *c = s->ctx;
+        HIP_TRY(c, hipSetDevice(c->device));
+        m->packed_nodes.resize((size_t)s->bvh.n_nodes * 64);
+        std::vector<float> rec(s->tri_mat.size() * 16);
+        if (!m->packed_nodes.empty()) HIP_TRY(c, hipMemcpy(m->packed_nodes.data(), s->d_nodes.p, m->packed_nodes.size(), hipMemcpyDeviceToHost));
+        if (!rec.empty()) HIP_TRY(c, hipMemcpy(rec.data(), s->d_tris.p, rec.size() * sizeof(float), hipMemcpyDeviceToHost));
+        m->bvh.tris.resize(s->tri_mat.size());
+        for (size_t i = 0; i < m->bvh.tris.size(); ++i) std::memcpy(&m->bvh.tris[i], &rec[i * 16], sizeof(BvhTri));
+        s->host_mirror = true;
+    }
     const uint64_t nb = s->node_bytes(), tb = (uint64_t)s->bvh.tris.size() * sizeof(BvhTri);
     if (node_bytes < nb || tri_bytes < tb || (nb && !nodes) || (tb && !tris48)) return fail(s->ctx, PT_ERR_INVALID_ARGUMENT, "buffers too small: need %llu + %llu bytes", (unsigned long long)nb, (unsigned long long)tb);
     if (nb) std::memcpy(nodes, s->node_data(), nb);

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -31,10 +33,22 @@ struct Tmp { Box box; int32_t left, right; uint32_t first, count; }; // count > 
 
 inline float pad_of(float c) { return 1e-6f * std::max(1.0f, std::fabs(c)); }
 
+inline Box tri_box(const float *verts9, uint32_t id) // the padded leaf box of docs/SPEC.md §4.1
+{
+    const float *p = verts9 + (size_t)id * 9;
+    Box b;
+    for (int k = 0; k < 3; ++k) {
+        const float lo = std::min(p[k], std::min(p[3 + k], p[6 + k])), hi = std::max(p[k], std::max(p[3 + k], p[6 + k]));
+        b.lo[k] = lo - pad_of(lo); b.hi[k] = hi + pad_of(hi);
+    }
+    return b;
+}
+
 struct Builder {
     const std::vector<Prim> &prims;
     std::vector<uint32_t> &idx;
     std::vector<Tmp> nodes;
+    uint32_t max_leaf = kMaxLeaf; // 1: every primitive its own leaf (the top-level build over LBVH clusters)
     Builder(const std::vector<Prim> &p, std::vector<uint32_t> &i) : prims(p), idx(i) { nodes.reserve(p.size()); }
 
     int32_t make_leaf(uint32_t b, uint32_t e, const Box &box)
@@ -80,7 +94,7 @@ struct Builder {
                 }
             }
             const float leaf_cost = box.area() * (float)n;
-            if (best_axis >= 0 && !(n <= kMaxLeaf && best >= leaf_cost)) {
+            if (best_axis >= 0 && !(n <= max_leaf && best >= leaf_cost)) {
                 const float ext = cb.hi[best_axis] - cb.lo[best_axis], sc = (float)kBins / ext, lo = cb.lo[best_axis];
                 const int ax = best_axis, bin = best_bin;
                 auto it = std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t id) {
@@ -90,10 +104,10 @@ struct Builder {
                 });
                 mid = (uint32_t)(it - idx.begin());
                 have_split = mid > b && mid < e;
-            } else if (n <= kMaxLeaf) return make_leaf(b, e, box);
+            } else if (n <= max_leaf) return make_leaf(b, e, box);
         }
         if (!have_split) {
-            if (n <= kMaxLeaf) return make_leaf(b, e, box);
+            if (n <= max_leaf) return make_leaf(b, e, box);
             int ax = 0; // median split along the widest centroid axis (ties: index order)
             for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;
             mid = b + n / 2;
@@ -215,47 +229,113 @@ void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint3
     out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-// A binary LBVH built on the device (lbvh.hip) -> blob. Subtrees of at most kMaxLeaf triangles become leaves (their
-// triangles are contiguous in Morton order), everything else keeps the device's topology and boxes.
+// A binary LBVH built on the device (lbvh.hip) -> blob, in two storeys:
+//   top    : the LBVH is cut where a subtree holds at most kClusterTris triangles; the host's binned-SAH builder makes a binary tree
+//            over those clusters (a few thousand boxes: milliseconds). Every ray crosses the top levels, and Morton splits are at
+//            their worst there (1M-triangle Cornell: 9.15 -> 7.9 node visits per ray).
+//   bottom : inside a cluster the device's topology and boxes are kept; subtrees of at most kMaxLeaf triangles become leaves unless
+//            splitting them lowers the SAH cost — the leaf rule of Builder::build (their triangles are contiguous in Morton order).
+#ifndef PT_LBVH_CLUSTER
+#define PT_LBVH_CLUSTER 256
+#endif
+constexpr uint32_t kClusterTris = PT_LBVH_CLUSTER; // 0: no SAH storey, the LBVH as it is
 void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out)
 {
     const auto t0 = std::chrono::steady_clock::now();
     out = BvhBlob{};
     out.width = width;
     if (n_tris < 2 || bt.order.size() != n_tris) return;
-    std::vector<Tmp> tn;
-    tn.reserve((size_t)n_tris * 2);
-    // iterative DFS from the root (deep LBVH chains stay off the C stack); tn grows, so child links are patched by index
-    int32_t root = -1;
-    struct Work { int32_t node; int32_t parent; int side; };
+    auto node_box = [&](int32_t c) {
+        Box b;
+        if (c >= 0) for (int k = 0; k < 3; ++k) { b.lo[k] = bt.box[(size_t)c * 6 + k]; b.hi[k] = bt.box[(size_t)c * 6 + 3 + k]; }
+        else b = tri_box(verts9, bt.order[(uint32_t)~c]); // single-triangle leaf: its padded box, exactly as the device made it
+        return b;
+    };
+    auto node_count = [&](int32_t c) { return c >= 0 ? bt.last[c] - bt.first[c] + 1 : 1u; };
+
+    // ---- cut: cluster roots, in Morton order
+    std::vector<int32_t> clusters;
+    {
+        std::vector<int32_t> st{ 0 };
+        while (!st.empty()) {
+            const int32_t c = st.back(); st.pop_back();
+            if (c < 0 || kClusterTris == 0 || node_count(c) <= kClusterTris) clusters.push_back(c);
+            else { st.push_back(bt.right[c]); st.push_back(bt.left[c]); }
+        }
+    }
+    // ---- top storey: binned SAH over the cluster boxes, one cluster per leaf
+    std::vector<Prim> prims(clusters.size());
+    std::vector<uint32_t> cidx(clusters.size());
+    for (size_t i = 0; i < clusters.size(); ++i) {
+        prims[i].box = node_box(clusters[i]);
+        for (int k = 0; k < 3; ++k) prims[i].c[k] = 0.5f * (prims[i].box.lo[k] + prims[i].box.hi[k]);
+        cidx[i] = (uint32_t)i;
+    }
+    Builder top(prims, cidx);
+    top.max_leaf = 1;
+    const int32_t root = top.build(0, (uint32_t)clusters.size(), 0);
+    std::vector<Tmp> tn = top.nodes;
+    tn.reserve(tn.size() + (size_t)n_tris * 2);
+
+    // ---- bottom storey: every top leaf is replaced, in place, by its cluster's LBVH subtree (iterative: deep chains stay off the C stack)
+    struct Work { int32_t node; int32_t at; }; // convert LBVH node `node` into tn[at]
     std::vector<Work> work;
-    work.push_back({ 0, -1, 0 });
+    const size_t n_top = tn.size();
+    for (size_t i = 0; i < n_top; ++i)
+        if (tn[i].count) work.push_back({ clusters[cidx[tn[i].first]], (int32_t)i });
     while (!work.empty()) {
         const Work w = work.back(); work.pop_back();
         Tmp t; t.left = t.right = -1; t.first = 0; t.count = 0;
+        t.box = node_box(w.node);
         if (w.node >= 0) {
-            const uint32_t f = bt.first[w.node], l = bt.last[w.node], cnt = l - f + 1;
-            for (int k = 0; k < 3; ++k) { t.box.lo[k] = bt.box[(size_t)w.node * 6 + k]; t.box.hi[k] = bt.box[(size_t)w.node * 6 + 3 + k]; }
-            if (cnt <= kMaxLeaf) { t.first = f; t.count = cnt; }
-        } else { // single-triangle leaf: its padded box is recomputed here exactly as the device did
-            const uint32_t j = (uint32_t)~w.node, id = bt.order[j];
-            const float *p = verts9 + (size_t)id * 9;
-            for (int k = 0; k < 3; ++k) {
-                const float lo = std::min(p[k], std::min(p[3 + k], p[6 + k])), hi = std::max(p[k], std::max(p[3 + k], p[6 + k]));
-                t.box.lo[k] = lo - pad_of(lo); t.box.hi[k] = hi + pad_of(hi);
+            const uint32_t f = bt.first[w.node], cnt = node_count(w.node);
+            if (cnt <= kMaxLeaf) {
+                float split_cost = 0.f;
+                for (const int32_t c : { bt.left[w.node], bt.right[w.node] }) split_cost += node_box(c).area() * (float)node_count(c);
+                if (!(split_cost < t.box.area() * (float)cnt)) { t.first = f; t.count = cnt; }
             }
-            t.first = j; t.count = 1;
-        }
-        const int32_t me = (int32_t)tn.size();
-        tn.push_back(t);
-        if (w.parent < 0) root = me; else if (w.side == 0) tn[w.parent].left = me; else tn[w.parent].right = me;
-        if (w.node >= 0 && t.count == 0) {
-            work.push_back({ bt.right[w.node], me, 1 });
-            work.push_back({ bt.left[w.node], me, 0 });
-        }
+            if (t.count == 0) {
+                t.left = (int32_t)tn.size(); t.right = t.left + 1;
+                tn.push_back(Tmp{}); tn.push_back(Tmp{});
+                work.push_back({ bt.left[w.node], t.left });
+                work.push_back({ bt.right[w.node], t.right });
+            }
+        } else { t.first = (uint32_t)~w.node; t.count = 1; }
+        tn[w.at] = t;
     }
+    const auto t1 = std::chrono::steady_clock::now();
     emit_blob(tn, root, bt.order, verts9, mats, n_tris, width, out);
+    if (getenv("PTRT_TIMING")) // developer aid
+        fprintf(stderr, "ptrt commit: lbvh device %.2f ms, cut + SAH top + conversion %.2f ms, emit_blob %.2f ms\n", bt.device_ms,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     out.build_ms = bt.device_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void build_sah_over_boxes(const float *boxes6, uint32_t n, std::vector<int32_t> &left, std::vector<int32_t> &right, std::vector<float> &node_boxes6, int32_t &root)
+{
+    std::vector<Prim> prims(n);
+    std::vector<uint32_t> idx(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) { prims[i].box.lo[k] = boxes6[(size_t)i * 6 + k]; prims[i].box.hi[k] = boxes6[(size_t)i * 6 + 3 + k]; }
+        for (int k = 0; k < 3; ++k) prims[i].c[k] = 0.5f * (prims[i].box.lo[k] + prims[i].box.hi[k]);
+        idx[i] = i;
+    }
+    Builder b(prims, idx);
+    b.max_leaf = 1;
+    const int32_t r = b.build(0, n, 0);
+    // internal Tmp nodes -> compact internal numbering; leaves -> ~box index
+    std::vector<int32_t> number(b.nodes.size(), -1);
+    int32_t n_int = 0;
+    for (size_t i = 0; i < b.nodes.size(); ++i) if (!b.nodes[i].count) number[i] = n_int++;
+    auto ref = [&](int32_t t) { return b.nodes[t].count ? ~(int32_t)idx[b.nodes[t].first] : number[t]; };
+    left.assign(n_int, 0); right.assign(n_int, 0); node_boxes6.assign((size_t)n_int * 6, 0.f);
+    for (size_t i = 0; i < b.nodes.size(); ++i) {
+        if (b.nodes[i].count) continue;
+        const int32_t k = number[i];
+        left[k] = ref(b.nodes[i].left); right[k] = ref(b.nodes[i].right);
+        for (int a = 0; a < 3; ++a) { node_boxes6[(size_t)k * 6 + a] = b.nodes[i].box.lo[a]; node_boxes6[(size_t)k * 6 + 3 + a] = b.nodes[i].box.hi[a]; }
+    }
+    root = ref(r);
 }
 
 // ---- BVH4Q: 64-byte nodes, child boxes quantised to 8 bits per coordinate on a per-node power-of-two grid

@@ -32,6 +32,19 @@ struct BinaryBvh {
 // pack a device-built binary tree into a width-2/4 blob (subtrees of <= 4 triangles become leaves)
 void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out);
 
+// Binned-SAH binary tree over n boxes (6 floats each), one box per leaf: children >= 0 internal node, < 0 leaf ~i (box i); node k's box in
+// node_boxes6. Used for the top storey of the GPU builder (a few thousand LBVH clusters).
+void build_sah_over_boxes(const float *boxes6, uint32_t n, std::vector<int32_t> &left, std::vector<int32_t> &right, std::vector<float> &node_boxes6, int32_t &root);
+
+// What the GPU builder leaves on the device when it also packs the tree (lbvh.hip build_lbvh_blob4q_device): BVH4Q nodes and 64-byte
+// triangle records in hipMalloc-ed arrays the caller takes over.
+struct DeviceBlob4Q {
+    void *nodes = nullptr; void *tris = nullptr; // n_nodes x 64 B, n_tris x 64 B
+    uint32_t n_nodes = 0, max_depth = 0, stack_need = 0;
+    float sah_cost = 0.f;
+    double device_ms = 0.0;
+};
+
 // BVH4Q (layout id 68): repack a width-4 blob into 64-byte nodes with 8-bit child boxes:
 //   +0 origin f32[3] | +12 exponent u8[3],0 | +16 ref i32[4] | +32 qlo_x,qlo_y,qlo_z u8[4] each | +44 qhi_x,qhi_y,qhi_z | +56 pad
 void quantize_bvh4(const BvhBlob &in, std::vector<uint8_t> &out);

@@ -132,6 +132,9 @@ void context_set_error(pt_context *c, const char *msg); // c == NULL: the callin
 
 // lbvh.hip: Morton sort + Karras hierarchy + refit on the device; returns the binary tree on the host
 struct BinaryBvh;
+struct DeviceBlob4Q;
 hipError_t build_lbvh_device(hipStream_t s, const float *verts9, uint32_t n_tris, BinaryBvh &out);
+// the same, packed into the BVH4Q blob + triangle records on the device (only the few-thousand-box top storey visits the host)
+hipError_t build_lbvh_blob4q_device(hipStream_t s, const float *verts9, const uint32_t *mats, uint32_t n_tris, DeviceBlob4Q &out);
 
 } // namespace ptrt
