@@ -471,8 +471,13 @@ PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint
 // Occupancy is worth more to this kernel than a few spills: it hides the latency of divergent node gathers with waves, and
 // unconstrained the fused variants take 84-89 VGPRs (5 waves/SIMD). Measured on the 1M-triangle Cornell box (Mrays/s):
 // 5 waves 9555, 6 waves 10326, 7 waves 10849 (SGPR spills only); the all-kinds variant spills 9 VGPRs at 7 and prefers 6.
+// Waves per SIMD the kernels are compiled for (amdgpu_waves_per_eu pins the register budget: 8 waves = 64 VGPRs, 7 = 72, 6 = 80).
+// Occupancy is what hides the latency of the dependent node gathers; measured on MI355X, one-ray-per-lane kernel, Grays/s:
+//   1M-triangle Cornell (BVH4Q, Lambert): 6 waves 12.5, 7 waves 13.5, 8 waves 14.0 (2 VGPRs spilled, outside the node loop);
+//   Cornell (BVH8Q, one node): 7 waves 29.9, 8 waves 25.4 — the wider node's visit does not fit 64 registers and there is no
+//   gather latency to hide. All-kinds shading (SHADE_INLINE) needs 76-80 registers: 6 waves, no spills.
 #ifndef PT_EXT_WAVES
-#define PT_EXT_WAVES(FUSE) ((FUSE) == SHADE_INLINE ? 6 : 7)
+#define PT_EXT_WAVES(L, FUSE) ((FUSE) == SHADE_INLINE ? 6 : (L) == PT_BVH_WIDTH_4Q ? 8 : 7)
 #endif
 // A lane's traversal stack: kStackLds entries in its LDS column ([level][lane]: conflict-free), the rest in a global
 // overflow column sized by the builder's exact worst case (pt_bvh_info.stack_need).
@@ -552,7 +557,7 @@ PT_DEV uint32_t leaf_step(const float4 *__restrict__ tris, const StackCtx &k, V3
 constexpr uint32_t kFinishVertices = 256;
 
 template <int L, bool COUNT, int FUSE>
-__global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(PT_EXT_WAVES(FUSE), PT_EXT_WAVES(FUSE)))) k_extend(ExtArgs a)
+__global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(PT_EXT_WAVES(L, FUSE), PT_EXT_WAVES(L, FUSE)))) k_extend(ExtArgs a)
 {
     // hot arguments (stay in SGPRs across the traversal loop); everything else goes through cold()
     const float4 *__restrict__ nodes = a.sc.nodes, *__restrict__ tris = a.sc.tris, *__restrict__ spheres = a.sc.spheres;

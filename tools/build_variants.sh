@@ -11,6 +11,6 @@ while [ $# -ge 2 ]; do
   /opt/rocm/bin/hipcc $F -c kernels.hip -o $d/kernels.o &
   /opt/rocm/bin/hipcc $F -x hip -c api.cpp -o $d/api.o &
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/variants/libptrt_$name.so $d/kernels.o $d/api.o lbvh.o bvh_build.o scenegen.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/variants/libptrt_$name.so $d/kernels.o $d/api.o comm.o lbvh.o bvh_build.o scenegen.o -ldl
   echo built $name "($flags)"
 done
