@@ -259,6 +259,39 @@ def test_comm_rccl_path_on_one_gpu(P, pto, renderer):
         P.Comm([renderer], root=1)
 
 
+def test_rccl_gather_aliases_the_tile_buffer(P, pto, renderer):
+    """What bench.py does between frames for N > 1, as far as one GPU can take it: a torch.distributed NCCL (= RCCL) process group
+    (one rank), the library's tile buffer aliased through __cuda_array_interface__ as the gather's send buffer (no copy), the stream
+    synchronised before the next frame, the gathered buffer un-tiled by pt_assemble_tiles."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from pathtracing_amd.distributed import gather_tiles
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_TESS, 30000, 5, 321, 200)
+    renderer.SetScene(sd, 0)
+    p = P.make_params(321, 200, spp=3, max_depth=6, streams=2)
+    renderer.Params = p
+    renderer.Render(0.0)
+    want = renderer.ReadFramebuffer()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29671")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        lay = P.tile_layout(p)
+        per_rank = lay.tiles_per_rank * lay.floats_per_tile
+        recv = torch.zeros(per_rank, dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            renderer.Render(0.0)
+            mine = torch.as_tensor(renderer.TilesDevice(), device="cuda")
+            assert mine.numel() == per_rank
+            dist.gather(mine, [recv], dst=0)  # gather_tiles() short-cuts world == 1; this is the collective it issues otherwise
+            torch.cuda.current_stream().synchronize()
+            renderer.AssembleTiles(recv.data_ptr(), recv.numel())
+            assert np.array_equal(renderer.ReadFramebuffer(), want)
+        assert gather_tiles(mine, per_rank, 0, 1, dist) is mine
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("streams", [2, 4, 7, 40])
 def test_sample_streams(P, pto, renderer, streams):
     """SPEC §5: K sample streams per pixel in flight, each with its own partial sum, summed in fixed order.
