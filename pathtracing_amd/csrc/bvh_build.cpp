@@ -12,7 +12,10 @@
 namespace ptrt {
 namespace {
 
-constexpr int kBins = 16;
+#ifndef PT_SAH_BINS
+#define PT_SAH_BINS 16
+#endif
+constexpr int kBins = PT_SAH_BINS;
 constexpr uint32_t kMaxLeaf = 4;
 constexpr int32_t kEmpty = 0x7fffffff;
 constexpr float kInf = std::numeric_limits<float>::infinity();

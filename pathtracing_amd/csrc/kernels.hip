@@ -451,7 +451,7 @@ PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint
 {
     if (compact) wave_push(&ps.counters[cnt_ext_index(cnext, shard)], q_next, alive, slot);
     else {
-        if (gid < total) q_next[gid] = alive ? slot : kInvalidSlot;
+        if (gid < total) at(q_next, gid) = alive ? slot : kInvalidSlot;
         if (gid == 0) ps.counters[cnt_ext_index(cnext, shard)] = total;
     }
     const uint64_t m = __ballot(alive);
@@ -473,11 +473,12 @@ PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint
 // 5 waves 9555, 6 waves 10326, 7 waves 10849 (SGPR spills only); the all-kinds variant spills 9 VGPRs at 7 and prefers 6.
 // Waves per SIMD the kernels are compiled for (amdgpu_waves_per_eu pins the register budget: 8 waves = 64 VGPRs, 7 = 72, 6 = 80).
 // Occupancy is what hides the latency of the dependent node gathers; measured on MI355X, one-ray-per-lane kernel, Grays/s:
-//   1M-triangle Cornell (BVH4Q, Lambert): 6 waves 12.5, 7 waves 13.5, 8 waves 14.0 (2 VGPRs spilled, outside the node loop);
+//   1M-triangle Cornell (BVH4Q, Lambert): 6 waves 12.5, 7 waves 13.5, 8 waves 14.0 (64 VGPRs, nothing spilled);
 //   Cornell (BVH8Q, one node): 7 waves 29.9, 8 waves 25.4 — the wider node's visit does not fit 64 registers and there is no
-//   gather latency to hide. All-kinds shading (SHADE_INLINE) needs 76-80 registers: 6 waves, no spills.
+//   gather latency to hide; all-kinds shading (SHADE_INLINE) fits 72 registers: 7 waves (Cornell + glass + metal 25.2 -> 26.0).
+// None of the non-counting instantiations spills or uses scratch (python tools/resources.py).
 #ifndef PT_EXT_WAVES
-#define PT_EXT_WAVES(L, FUSE) ((FUSE) == SHADE_INLINE ? 6 : (L) == PT_BVH_WIDTH_4Q ? 8 : 7)
+#define PT_EXT_WAVES(L, FUSE) ((L) == PT_BVH_WIDTH_4Q && (FUSE) != SHADE_INLINE ? 8 : 7)
 #endif
 // A lane's traversal stack: kStackLds entries in its LDS column ([level][lane]: conflict-free), the rest in a global
 // overflow column sized by the builder's exact worst case (pt_bvh_info.stack_need).
@@ -573,7 +574,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     const uint32_t gid = bx * kExtBlock + tid;                  // index inside the shard's queue
     uint32_t n, n_alive, slot = kInvalidSlot, n_bounces;
     bool do_compact;
-    size_t qbase;
+    uint32_t qbase; // first entry of this shard's region of the queues (entries: 32-bit offsets like the slot arrays, see at())
     {
         const PathState &ps = cold().ps;
         n = ps.counters[cnt_ext_index(ccur, shard)]; n_alive = ps.counters[cnt_alive_index(ccur, shard)];
@@ -587,8 +588,8 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
             if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
         }
         if (bx * kExtBlock >= n || n_alive == 0u) return;
-        qbase = (size_t)shard * ps.shard_cap;
-        if (gid < n) slot = ps.q_ext[parity][qbase + gid];
+        qbase = shard * ps.shard_cap;
+        if (gid < n) slot = at(ps.q_ext[parity], qbase + gid);
         // FUSE: up to `bounces` path vertices per launch with the path state in registers (a terminated path continues with
         // its stream's next camera ray, so most lanes stay busy); the state goes back to memory once, at the end.
         // Once few paths are left in the shard (the frame's tail) the launch runs them to their end instead (bounded by
@@ -600,7 +601,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
         n_bounces = FUSE == SHADE_NONE ? 1u : (n_alive <= ps.finish_below ? kFinishVertices : sparse ? 1u : a.bounces);
     }
     const bool active = slot != kInvalidSlot;                  // holes: paths that ended since the queue was last compacted
-    const StackCtx stk{ s_stack, kExtBlock, tid, (uint32_t)qbase + gid };
+    const StackCtx stk{ s_stack, kExtBlock, tid, qbase + gid };
 
     unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0, c_wave_iters = 0, c_wave_iters_late = 0;
     PathRegs r;
@@ -679,7 +680,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     }
     if (FUSE != SHADE_NONE) {
         if (alive) path_store(ps, slot, r);
-        queue_next(ps, shard, cnext, ps.q_ext[parity ^ 1u] + qbase, gid, n, alive, slot, do_compact);
+        queue_next(ps, shard, cnext, &at(ps.q_ext[parity ^ 1u], qbase), gid, n, alive, slot, do_compact);
         if (wave_rays && lane_id() == 0u) atomicAdd(traced_counter(ps, cnext, shard), (unsigned long long)wave_rays);
     }
 }
