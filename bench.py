@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the all-threads oracle leg; the full frame is rendered "
                                                                     "(and compared) when it fits, else a lower spp (then no RMSE)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="with --gpus 1: run the N > 1 exchange (RCCL group of one rank, pipelined gather, un-tiling) anyway and check the "
+                         "assembled frame against the plain one - the multi-GPU code path as far as one GPU can take it")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 ranks on ONE GPU over gloo (CPU-staged gather): rehearsal of the N>1 code path, not a measurement")
     args = ap.parse_args()
@@ -71,7 +74,7 @@ def main():
     import torch
     import torch.distributed as dist
     import pathtracing_amd as P
-    from pathtracing_amd.distributed import gather_tiles
+    from pathtracing_amd.distributed import gather_tiles, PipelinedGather
     N = P.native
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,11 +86,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libptrt has no CPU path")
     device = 0 if args.rehearse_gloo else local_rank
     torch.cuda.set_device(device)
-    if world > 1:
+    exchange = world > 1 or args.force_exchange
+    if exchange:
         if args.rehearse_gloo:
             dist.init_process_group("gloo")
-        else:
+        elif world > 1:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))  # nccl == RCCL on ROCm
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29677")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", device))
 
     kinds = {"cornell_tess": N.PT_SCENE_CORNELL_TESS, "cornell": N.PT_SCENE_CORNELL, "cornell_glass": N.PT_SCENE_CORNELL_GLASS,
              "soup": N.PT_SCENE_TRIANGLE_SOUP}
@@ -115,34 +122,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    recv = None  # rank 0's receive buffer for the gather, allocated once
-    if world > 1 and rank == 0 and not args.rehearse_gloo:
-        recv = torch.empty(world * per_rank, dtype=torch.float32, device="cuda")
+    pipe = PipelinedGather(r, per_rank, rank, world, dist) if exchange and not args.rehearse_gloo else None
 
     def step():
         st = r.Render(0.0)  # synchronous: all kernels of this rank's tiles are done on return
-        if world > 1:
-            mine = torch.as_tensor(r.TilesDevice(), device="cuda")  # aliases the library's tile buffer (no copy)
-            if args.rehearse_gloo:
-                got = gather_tiles(mine.cpu(), per_rank, rank, world, dist)
-                got = got.cuda() if rank == 0 else None
-            else:
-                got = gather_tiles(mine, per_rank, rank, world, dist, out=recv)  # the one exchange step: tile radiance to rank 0 over xGMI
-                # the send reads the library's buffer on torch's stream while the next Render (library streams) rewrites it:
-                # every rank waits for its part of the gather before it renders again (pt_tiles_device_ptr's ownership rule)
-                torch.cuda.current_stream().synchronize()
+        if pipe:
+            pipe.submit()  # the one exchange step (tile radiance to rank 0 over xGMI), overlapped with the next frame's rendering
+        elif exchange:  # gloo rehearsal: CPU-staged, in line
+            mine = torch.as_tensor(r.TilesDevice(), device="cuda")
+            got = gather_tiles(mine.cpu(), per_rank, rank, world, dist)
             if rank == 0:
+                got = got.cuda()
                 r.AssembleTiles(got.data_ptr(), got.numel())
         return st
 
     for _ in range(args.warmup):
         step()
+    if pipe:
+        pipe.finish()
     barrier()
     t0 = time.perf_counter()
     rays = 0
     for _ in range(args.steps):
         st = step()
         rays += st.rays
+    if pipe:
+        pipe.finish()  # inside the timed region: the last frame's gather and un-tiling
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_choice = KERNEL_NAMES[int(st.reserved[0])]
@@ -157,11 +162,12 @@ def main():
     else:
         rays_all = float(rays)
 
-    if world > 1 and args.rehearse_gloo and rank == 0:
+    if exchange and (args.rehearse_gloo or args.force_exchange) and rank == 0:
         # the rehearsal also proves the partition: the assembled frame must equal a single-rank frame bit for bit
         r.Params = mk()
         r.Render(0.0)
         assert np.array_equal(r.ReadFramebuffer(), frame), "multi-rank frame differs from the single-rank frame"
+        assert frame[..., 3].min() == 1.0, "the gathered frame is incomplete"
         r.Params = params
 
     out = None
@@ -175,7 +181,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "rays_per_frame": int(rays_all / args.steps), "bvh_build_s": round(commit_s, 2),
-                       "extend_kernel": kernel_choice, "parallelism": f"tiles{world}" + ("-gloo-rehearsal" if args.rehearse_gloo else "")},
+                       "extend_kernel": kernel_choice, "parallelism": f"tiles{world}" + ("-gloo-rehearsal" if args.rehearse_gloo else "-exchange-forced" if args.force_exchange else "")},
         }
 
     single = rank == 0 and world == 1
@@ -215,7 +221,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     r.Dispose()
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
 

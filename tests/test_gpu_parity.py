@@ -292,6 +292,25 @@ def test_rccl_gather_aliases_the_tile_buffer(P, pto, renderer):
         dist.destroy_process_group()
 
 
+def test_bench_exchange_path_on_one_gpu():
+    """bench.py --force-exchange: the N > 1 frame loop (RCCL process group, PipelinedGather: staging copy, gather on a side stream
+    overlapped with the next frame, deferred un-tiling, double buffering) with a group of one rank; bench.py itself asserts that the
+    assembled frame equals the plain frame. Also run under a 2-rank gloo group (CPU-staged gather) as the driver launches N > 1."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--scene", "cornell_tess", "--tris", "40000", "--width", "640", "--height", "360", "--spp", "8", "--steps", "5", "--warmup", "2",
+              "--no-cpu-baseline", "--no-roofline", "--no-configs"]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-exchange"] + common, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["parallelism"] == "tiles1-exchange-forced" and line["value"] > 0
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-gloo"] + common, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+
+
 @pytest.mark.parametrize("streams", [2, 4, 7, 40])
 def test_sample_streams(P, pto, renderer, streams):
     """SPEC §5: K sample streams per pixel in flight, each with its own partial sum, summed in fixed order.
