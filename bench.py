@@ -45,8 +45,8 @@ KERNEL_NAMES = {0: "unprobed", 1: "k_extend", 2: "k_extend_packed", 3: "k_extend
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="cornell_tess", choices=["cornell_tess", "cornell", "cornell_glass", "soup"])
     ap.add_argument("--tris", type=int, default=1 << 20)
     ap.add_argument("--width", type=int, default=1920)
@@ -58,6 +58,9 @@ def main():
                          "in registers over several vertices and refills a finished path from its own stream, so it wants samples "
                          "per stream more than it wants slots; and with one K the N-rank frame is the single-rank frame bit for bit")
     ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default (68 = BVH4Q)")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "simple", "packed", "pool"],
+                    help="extend kernel: auto = probed per scene in the first frame (the default), else forced (profiling passes force it so that "
+                         "no probe iteration sits inside the one profiled frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline and parity)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
@@ -108,8 +111,10 @@ def main():
     commit_s = time.time() - t0
     info = r.BvhInfo()
 
+    kflag = {"auto": 0, "simple": N.PT_FLAG_EXTEND_SIMPLE, "packed": N.PT_FLAG_EXTEND_PACKED, "pool": N.PT_FLAG_EXTEND_POOL}[args.kernel]
+
     def mk(**kw):
-        return P.make_params(W, H, spp=kw.pop("spp", args.spp), max_depth=args.max_depth, streams=args.streams, **kw)
+        return P.make_params(W, H, spp=kw.pop("spp", args.spp), max_depth=args.max_depth, streams=args.streams, flags=kw.pop("flags", 0) | kflag, **kw)
 
     params = mk(rank=rank, nranks=world)
     r.Params = params

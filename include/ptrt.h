@@ -118,7 +118,7 @@ typedef struct {
     uint64_t paths;
     uint64_t node_visits, tri_tests, sphere_tests; /* only with PT_FLAG_COUNT_VISITS, else 0 */
     uint32_t iterations;    /* wavefront iterations = launches of the extend kernel; the default (fused) kernel advances every
-                               path by up to max_depth / 2 clamped to [4, 8] vertices per iteration (PTRT_BOUNCES overrides) */
+                               path by up to max_depth / 2 clamped to [4, 8] vertices per iteration (pt_tuning.bounces overrides) */
     uint32_t extend_launches;
     double gpu_ms;          /* hipEvent start->stop around all kernels of the frame */
     double extend_ms;       /* sum of extend-kernel durations (PT_FLAG_PROFILE_KERNELS); includes shading when fused */
@@ -144,10 +144,28 @@ typedef struct {
                                 size a global overflow area from this */
 } pt_bvh_info;
 
+/* Scheduling knobs of a context (none changes a pixel; tests/test_gpu_parity.py holds every setting to the same frame). Read the
+ * current values with pt_context_get_tuning, change what you want, write them back. The library reads no environment variables for
+ * these (two stderr diagnostics aside: PTRT_TRACE, PTRT_TIMING). */
+typedef struct {
+    uint32_t bounces;       /* path vertices a lane advances per launch of the fused extend kernels, 1..64; 0 (default) = max_depth / 2
+                               clamped to [4, 8] */
+    uint32_t loops;         /* independent shard-group wavefront loops per frame, each on its own stream: 1, 2 or 4; 0 (default) = two for
+                               frames of at most 12 M slots (a rank's share), else one */
+    uint32_t finish_below;  /* a shard with at most this many live paths runs them to their end in one launch (default 4096; 0 = never) */
+    uint32_t packed_chunk;  /* queue entries per wavefront of the lane-packing kernel, >= 64; 0 (default) = 256 with >= 4 streams, else 128 */
+    float compact_below;    /* a shard re-packs its queue in an iteration that starts with alive < this * length (default 0.9; > 1 every
+                               iteration; 0 never) */
+    float sparse_below;     /* one-ray-per-lane kernel: a launch that starts with alive < this * length advances one vertex only (default 0 = off) */
+    uint32_t reserved[2];
+} pt_tuning; /* 32 B */
+
 /* ---- context: replaces GraphicsDevice.Init (GraphicsDevice.cs:38-43) + Renderer.CreateResources (Renderer.cs:105-196) */
 pt_status pt_context_create(const pt_device_desc *desc, pt_context **out);
 void pt_context_destroy(pt_context *ctx);                 /* Renderer.Dispose, Renderer.cs:1192-1216 */
 const char *pt_last_error(const pt_context *ctx);         /* ctx may be NULL: last error of the calling thread */
+pt_status pt_context_get_tuning(const pt_context *ctx, pt_tuning *out);
+pt_status pt_context_set_tuning(pt_context *ctx, const pt_tuning *tuning);
 uint32_t pt_abi_version(void);
 
 /* ---- scene: the reference has only shader literals (Test.hlsl:6,8,12,13); this is the API that replaces them */

@@ -75,6 +75,11 @@ class pt_bvh_info(C.Structure):
                 ("sah_cost", C.c_float), ("stack_need", C.c_uint32)]
 
 
+class pt_tuning(C.Structure):
+    _fields_ = [("bounces", C.c_uint32), ("loops", C.c_uint32), ("finish_below", C.c_uint32), ("packed_chunk", C.c_uint32),
+                ("compact_below", C.c_float), ("sparse_below", C.c_float), ("reserved", C.c_uint32 * 2)]
+
+
 class pt_tile_layout(C.Structure):
     _fields_ = [("tile_size", C.c_uint32), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("n_tiles", C.c_uint32),
                 ("tiles_mine", C.c_uint32), ("tiles_per_rank", C.c_uint32), ("floats_per_tile", C.c_uint64)]
@@ -84,7 +89,7 @@ class pt_scene_counts(C.Structure):
     _fields_ = [("n_tris", C.c_uint64), ("n_spheres", C.c_uint64), ("n_mats", C.c_uint64)]
 
 
-assert C.sizeof(pt_material) == 48 and C.sizeof(pt_camera) == 64 and C.sizeof(pt_render_params) == 64
+assert C.sizeof(pt_material) == 48 and C.sizeof(pt_camera) == 64 and C.sizeof(pt_render_params) == 64 and C.sizeof(pt_tuning) == 32
 
 _vp, _u32, _u64, _st = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
 _P = C.POINTER
@@ -95,6 +100,8 @@ SYMBOLS = {
     "pt_context_create": (_st, [_P(pt_device_desc), _P(_vp)]),
     "pt_context_destroy": (None, [_vp]),
     "pt_last_error": (C.c_char_p, [_vp]),
+    "pt_context_get_tuning": (_st, [_vp, _P(pt_tuning)]),
+    "pt_context_set_tuning": (_st, [_vp, _P(pt_tuning)]),
     "pt_scene_create": (_st, [_vp, _P(_vp)]),
     "pt_scene_destroy": (None, [_vp]),
     "pt_scene_set_triangles": (_st, [_vp, _vp, _vp, _u64]),

@@ -68,21 +68,22 @@ struct pt_context {
     hipEvent_t ev_lag[kMaxGroups][kLag] = {};
     hipStream_t group_stream[kMaxGroups] = {}; // group 0 runs on `stream` when there is one group only
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups] = {};
-    uint32_t groups = 0;                        // PTRT_GROUPS (1, 2, 4) overrides; 0 = by frame size: frames of <= kTwoLoopsBelow slots run
+    uint32_t groups = 0;                        // pt_tuning.loops (1, 2, 4) overrides; 0 = by frame size: frames of <= kTwoLoopsBelow slots run
                                                 // two loops, whose launch tails overlap (1M-tri Cornell: a rank's 1/8 of the 1080p frame
                                                 // 4.11 -> 3.81 ms, 1/4 7.14 -> 6.62 ms; four loops are slower, the host cannot feed them).
                                                 // Big frames (the 1-GPU headline: 16.6 M slots) keep one loop: the gain is 3 % there, and a
                                                 // launch timed by HIP events, by rocprofv3 and in the benchmark frame stays one and the same thing
-    uint32_t bounces = 0;                       // PTRT_BOUNCES (1..64): path vertices per launch of the fused kernel (state in registers);
+    uint32_t bounces = 0;                       // pt_tuning.bounces (1..64): path vertices per launch of the fused kernel (state in registers);
                                                 // 0 = max_depth / 2 clamped to [4, 8] (measured: depth 8 -> 4 is best, 12.9 vs 12.3 Grays/s at 8;
                                                 // depth 16 with glass -> 8 is best, 23.0 vs 20.6 at 4)
-    double compact_below = 0.9;                // PTRT_COMPACT overrides: a shard re-packs its queue in an iteration that starts with
+    double compact_below = 0.9;                // pt_tuning.compact_below: a shard re-packs its queue in an iteration that starts with
                                                 // alive/length below this (>1 = every iteration, 0 = never); else carried in place.
                                                 // Measured (1M-tri Cornell): 1080p/64spp 0.75: 10786, 0.9: 11190, always: 11354 Mrays/s;
                                                 // 4K/1024spp 0.9: 12471, always: 11430 — re-packing mixes wavefronts, long frames feel it
-    double sparse_below = 0.0;                  // PTRT_SPARSE (0 = off, the default: measured ±0): see PathState::sparse_below
-    uint32_t finish_below = 4096;             // PTRT_FINISH overrides: a shard with no more alive paths than this runs them to
+    double sparse_below = 0.0;                  // pt_tuning.sparse_below (0 = off, the default: measured ±0): see PathState::sparse_below
+    uint32_t finish_below = 4096;             // pt_tuning.finish_below: a shard with no more alive paths than this runs them to
                                                 // their end in one launch of the fused kernel (0 = never)
+    uint32_t packed_chunk = 0;                  // pt_tuning.packed_chunk: queue entries per wavefront of the lane-packing kernel (0 = by stream count)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_probe[4] = {}; // brackets of the two probe iterations that pick the extend kernel
     std::vector<hipEvent_t> ev_pool;
@@ -99,9 +100,9 @@ struct pt_scene {
     pt_camera cam{};
     float sky[3] = { 0.f, 0.f, 0.f };
     bool have_cam = false, committed = false;
-    BvhBlob bvh;
+    mutable BvhBlob bvh;                 // (mutable: pt_scene_bvh_read fills the host copy of a device-packed blob on first use)
     uint32_t layout = 0;                 // PT_BVH_WIDTH_* the scene was committed with
-    std::vector<uint8_t> packed_nodes;   // layouts PT_BVH_WIDTH_4Q / _8Q: the 64- / 128-byte nodes that are uploaded / read back
+    mutable std::vector<uint8_t> packed_nodes; // layouts PT_BVH_WIDTH_4Q / _8Q: the 64- / 128-byte nodes that are uploaded / read back
     bool device_packed = false;          // the blob was packed on the device (lbvh.hip build_lbvh_blob4q_device): the host copies below
     mutable bool host_mirror = true;     // (packed_nodes, bvh.tris) are fetched from the device the first time pt_scene_bvh_read wants them
     bool quantised() const { return layout == PT_BVH_WIDTH_4Q || layout == PT_BVH_WIDTH_8Q; }
@@ -201,11 +202,6 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
         c->own_stream = true;
     }
     bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * (kFinalOffset + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
-    if (const char *e = getenv("PTRT_GROUPS")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4) c->groups = (uint32_t)g; }
-    if (const char *e = getenv("PTRT_BOUNCES")) { const int b = atoi(e); if (b >= 1 && b <= 64) c->bounces = (uint32_t)b; }
-    if (const char *e = getenv("PTRT_SPARSE")) { const double v = atof(e); if (v >= 0.0 && v <= 1.0) c->sparse_below = v; }
-    if (const char *e = getenv("PTRT_FINISH")) { const long v = atol(e); if (v >= 0 && v <= (1l << 30)) c->finish_below = (uint32_t)v; }
-    if (const char *e = getenv("PTRT_COMPACT")) { const double v = atof(e); if (v >= 0.0 && v <= 2.0) c->compact_below = v; }
     for (uint32_t g = 0; ok && g < kMaxGroups; ++g) {
         ok = hipStreamCreateWithFlags(&c->group_stream[g], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) == hipSuccess;
@@ -218,6 +214,28 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
     ok = ok && c->counters.ensure(kCntTotalWords) == hipSuccess;
     if (!ok) { pt_context_destroy(c); return fail(nullptr, PT_ERR_HIP, "context resource creation failed"); }
     *out = c;
+    return PT_OK;
+}
+
+pt_status pt_context_get_tuning(const pt_context *c, pt_tuning *o)
+{
+    if (!c || !o) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "pt_context_get_tuning: NULL argument");
+    std::memset(o, 0, sizeof *o);
+    o->bounces = c->bounces; o->loops = c->groups; o->finish_below = c->finish_below; o->packed_chunk = c->packed_chunk;
+    o->compact_below = (float)c->compact_below; o->sparse_below = (float)c->sparse_below;
+    return PT_OK;
+}
+
+pt_status pt_context_set_tuning(pt_context *c, const pt_tuning *t)
+{
+    if (!c || !t) return fail(c, PT_ERR_INVALID_ARGUMENT, "pt_context_set_tuning: NULL argument");
+    if (t->bounces > 64) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: bounces must be 0 (default) or 1..64");
+    if (t->loops != 0 && t->loops != 1 && t->loops != 2 && t->loops != 4) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: loops must be 0 (default), 1, 2 or 4");
+    if (t->packed_chunk != 0 && (t->packed_chunk < 64 || t->packed_chunk > (1u << 20))) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: packed_chunk must be 0 (default) or 64..2^20");
+    if (!(t->compact_below >= 0.f && t->compact_below <= 2.f) || !(t->sparse_below >= 0.f && t->sparse_below <= 1.f))
+        return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: compact_below must be in [0,2], sparse_below in [0,1]");
+    c->bounces = t->bounces; c->groups = t->loops; c->finish_below = t->finish_below; c->packed_chunk = t->packed_chunk;
+    c->compact_below = t->compact_below; c->sparse_below = t->sparse_below;
     return PT_OK;
 }
 
@@ -446,7 +464,7 @@ pt_status pt_scene_bvh_read(const pt_scene *s, void *nodes, uint64_t node_bytes,
     if (!s) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "scene is NULL");
     if (!s->committed) return fail(s->ctx, PT_ERR_NOT_COMMITTED, "scene not committed");
     if (!s->host_mirror) { // packed on the device: fetch the blob now (nodes as they are, triangles = rows 0-2 of the 64-byte records)
-        pt_scene *m = const_cast<pt_scene *>(s); // fills the host copies the scene owns; device data and results are untouched
+        const pt_scene *m = s; // fills the (mutable) host copies the scene owns; device data and results are untouched
         pt_context *c = s->ctx;
         HIP_TRY(c, hipSetDevice(c->device));
         m->packed_nodes.resize((size_t)s->bvh.n_nodes * 64);
@@ -506,14 +524,12 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     pt_stats out; std::memset(&out, 0, sizeof out);
     c->fb_valid = false;
     const bool profile = (p->flags & PT_FLAG_PROFILE_KERNELS) != 0, count = (p->flags & PT_FLAG_COUNT_VISITS) != 0;
-    static const uint32_t chunk_env = [] { const char *e = getenv("PTRT_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }(); // tuning aid
     // rays per wavefront of the lane-packing kernel: 256 once several sample streams keep the queues long, else 128 (measured)
-    const uint32_t packed_chunk = chunk_env >= 64u ? chunk_env : ((p->streams >= 4u) ? 256u : 128u);
+    const uint32_t packed_chunk = c->packed_chunk >= 64u ? c->packed_chunk : ((p->streams >= 4u) ? 256u : 128u);
     const bool bucket_specular = (p->flags & PT_FLAG_BUCKET_SPECULAR) != 0;
     const bool split_kernels = bucket_specular || (p->flags & PT_FLAG_SPLIT_KERNELS) != 0;
-    static const uint32_t kernel_env = [] { const char *e = getenv("PTRT_KERNEL"); return e ? (uint32_t)atoi(e) : 0u; }(); // tuning aid: 1, 2, 3
     const uint32_t forced_choice = (p->flags & PT_FLAG_EXTEND_POOL) ? (uint32_t)EXT_POOL : (p->flags & PT_FLAG_EXTEND_PACKED) ? (uint32_t)EXT_PACKED
-                                   : (p->flags & PT_FLAG_EXTEND_SIMPLE) ? (uint32_t)EXT_SIMPLE : (kernel_env >= 1u && kernel_env <= 3u) ? kernel_env : 0u;
+                                   : (p->flags & PT_FLAG_EXTEND_SIMPLE) ? (uint32_t)EXT_SIMPLE : 0u;
 
     if (p->mode == PT_REFERENCE_SPHERE) {
         // Renderer.ComputeFrame: one dispatch, then the host blocks on the fence (Renderer.cs:1020,1036,972)

@@ -138,6 +138,21 @@ class Renderer:
         desc = N.pt_device_desc(self._device, self._stream, 0, 0)
         _check(N.lib.pt_context_create(C.byref(desc), C.byref(self._ctx)))
 
+    def GetTuning(self):
+        t = N.pt_tuning()
+        _check(N.lib.pt_context_get_tuning(self._ctx, C.byref(t)), self._ctx)
+        return t
+
+    def SetTuning(self, **kw):
+        """Scheduling knobs of the context (include/ptrt.h pt_tuning: bounces, loops, finish_below, packed_chunk, compact_below,
+        sparse_below). None changes a pixel."""
+        t = self.GetTuning()
+        for k, v in kw.items():
+            if not hasattr(t, k) or k == "reserved":
+                raise AttributeError(f"pt_tuning has no field {k!r}")
+            setattr(t, k, v)
+        _check(N.lib.pt_context_set_tuning(self._ctx, C.byref(t)), self._ctx)
+
     def SetScene(self, scene, bvh_width=0):
         """Upload a SceneData and build its BVH (the reference has no scene API; Test.hlsl:6,8,12,13 are literals)."""
         ctx = self._ctx

@@ -139,7 +139,7 @@ def test_csharp_binding_matches_the_header():
 
 def test_every_header_struct_and_function_was_seen():
     hs, hf, he = parse_header(open(HEADER).read())
-    assert set(hs) == {"PtDeviceDesc", "PtMaterial", "PtCamera", "PtRenderParams", "PtStats", "PtBvhInfo", "PtTileLayout", "PtSceneCounts"}
+    assert set(hs) == {"PtDeviceDesc", "PtMaterial", "PtCamera", "PtRenderParams", "PtStats", "PtBvhInfo", "PtTileLayout", "PtSceneCounts", "PtTuning"}
     import pathtracing_amd._native as N
     assert set(hf) == set(N.SYMBOLS), set(hf) ^ set(N.SYMBOLS)  # the parser sees exactly the entry points the ctypes binding declares
     assert he["PT_FLAG_EXTEND_POOL"] == 128 and he["PT_ERR_INTERNAL"] == 7 and he["PT_BVH_WIDTH_8Q"] == 72

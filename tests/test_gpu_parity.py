@@ -416,14 +416,14 @@ def test_bucketed_specular_shading_is_identical(P, pto, renderer):
 
 
 def test_shard_groups_on_separate_streams(P, pto, monkeypatch):
-    """PTRT_GROUPS=2/4: the 64 queue shards run as 2/4 independent wavefront loops on their own HIP streams (api.cpp).
+    """pt_tuning.loops = 2/4: the 64 queue shards run as 2/4 independent wavefront loops on their own HIP streams (api.cpp).
     Shards never exchange slots, so the frame and the ray count must not change."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 4, 300, 200)
     p = P.make_params(300, 200, spp=6, max_depth=10, streams=4)
     frames = []
     for groups in ("1", "2", "4"):
-        monkeypatch.setenv("PTRT_GROUPS", groups)
         r = P.Renderer(P.Window(300, 200)); r.Init()
+        r.SetTuning(loops=int(groups))
         try:
             r.SetScene(sd, 0); r.Params = p
             st = r.Render(0.0)
@@ -439,15 +439,15 @@ def test_shard_groups_on_separate_streams(P, pto, monkeypatch):
 
 @pytest.mark.parametrize("flags", [0, 4, 128, 64, 68])  # fused one-ray-per-lane / lane-packing / pooled kernels, and the first two followed by k_shade (PT_FLAG_SPLIT_KERNELS)
 def test_queue_compaction_policy_is_invisible(P, pto, monkeypatch, flags):
-    """PTRT_COMPACT: queues carried over in place with holes (0 = never re-packed), re-packed every iteration (2), or
+    """pt_tuning.compact_below: queues carried over in place with holes (0 = never re-packed), re-packed every iteration (2), or
     re-packed when alive/length < 0.9 — scheduling only: frame and ray count stay the oracle's. The streams end at
     different iterations (spp 7 over 4 streams, Russian roulette), so the in-place runs do see holes."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 4, 200, 150)
     p = P.make_params(200, 150, spp=7, max_depth=12, streams=4, flags=flags)
     frames = []
     for thr in ("0", "2", "0.9", "0.5"):
-        monkeypatch.setenv("PTRT_COMPACT", thr)
         r = P.Renderer(P.Window(200, 150)); r.Init()
+        r.SetTuning(compact_below=float(thr))
         try:
             r.SetScene(sd, 0); r.Params = p
             st = r.Render(0.0)
@@ -464,16 +464,18 @@ def test_queue_compaction_policy_is_invisible(P, pto, monkeypatch, flags):
 
 @pytest.mark.parametrize("kflag", [8, 128])  # one ray per lane, pooled
 def test_bounces_per_launch_is_invisible(P, pto, monkeypatch, kflag):
-    """PTRT_BOUNCES: the fused kernel advances a path by 1, 3 or 16 vertices per launch with its state in registers
+    """pt_tuning.bounces: the fused kernel advances a path by 1, 3 or 16 vertices per launch with its state in registers
     (kernels.hip k_extend). Same arithmetic per vertex, so frame, ray count and visit counters stay the oracle's."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 4, 160, 120)
     p = P.make_params(160, 120, spp=5, max_depth=9, streams=2, flags=P.native.PT_FLAG_COUNT_VISITS | kflag)
     got = []
-    # PTRT_FINISH: shards with no more alive paths than this run them to their end in one launch (0 = never, 1000000 = always)
+    # pt_tuning.finish_below: shards with no more alive paths than this run them to their end in one launch (0 = never, 1000000 = always)
     for b, finish in (("1", "0"), ("3", "0"), ("16", "0"), ("2", "1000000")):
-        monkeypatch.setenv("PTRT_BOUNCES", b)
-        monkeypatch.setenv("PTRT_FINISH", finish)
         r = P.Renderer(P.Window(160, 120)); r.Init()
+        r.SetTuning(bounces=int(b), finish_below=int(finish))
+        assert r.GetTuning().bounces == int(b)
+        with pytest.raises(P.PtException):
+            r.SetTuning(loops=3)
         try:
             r.SetScene(sd, 0); r.Params = p
             st = r.Render(0.0)

@@ -61,7 +61,7 @@ with open(os.path.join(src, "trace", "trace_kernel_stats.csv")) as fh:
 clock = pl["GRBM_GUI_ACTIVE"] / 8.0 / avg_ns if avg_ns and "GRBM_GUI_ACTIVE" in pl else None  # GHz; GUI_ACTIVE is summed over the 8 XCDs
 
 with open(os.path.join(out, "counters_dominant_kernel.txt"), "w") as f:
-    f.write(f"rocprofv3 --pmc passes (tools/profile_pmc.sh: one counter group per run) over `PTRT_KERNEL=1 python3 bench.py --steps 1 --warmup 0 "
+    f.write(f"rocprofv3 --pmc passes (tools/profile_pmc.sh: one counter group per run) over `python3 bench.py --kernel simple --steps 1 --warmup 0 "
             f"--no-cpu-baseline --no-roofline`\n(MI355X; sums over the frame's {n} launches of {dom}; {rays_per_frame} rays per frame)\n\n")
     for c in sorted(per[dom]):
         f.write(f"{c:40s} {per[dom][c]:14.6g}   per launch {pl[c]:14.6g}\n")
@@ -82,7 +82,7 @@ key = json.load(open(os.path.join(src, "workload_key.json")))
 latest = {
     "workload_key": key, "kernel": dom, "launches_profiled": n, "rays_per_launch": rays_per_frame / n,
     "per_launch": {c: pl[c] for c in sorted(pl)}, "hbm_bytes_per_launch": round(hbm), "effective_clock_ghz": round(clock, 2) if clock else None,
-    "source": f"{out}/pmc_per_kernel.csv: rocprofv3 --pmc, one counter group per run, over `PTRT_KERNEL=1 bench.py --steps 1 --warmup 0 --no-cpu-baseline "
+    "source": f"{out}/pmc_per_kernel.csv: rocprofv3 --pmc, one counter group per run, over `bench.py --kernel simple --steps 1 --warmup 0 --no-cpu-baseline "
               f"--no-roofline --no-configs`; means over the {n} launches of {dom} in the frame; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
               "(FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section)",
     "workload": line["config"]["workload"],

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer aid (GPU box): rocprofv3 counter passes over one frame of the bench workload (`bench.py --steps 1 --warmup 0 --no-configs`), each
 # group of counters in its own run (never together with a trace), summarised per kernel by tools/pmc_summary.py.
-# usage: tools/profile_pmc.sh <outdir> [bench.py args...]      env: PTRT_KERNEL=1|2|3 forces the extend kernel
+# usage: tools/profile_pmc.sh <outdir> [bench.py args...]      e.g. --kernel simple to force the extend kernel
 out=$1; shift
 export TMPDIR=/tmp
 mkdir -p "$out"
