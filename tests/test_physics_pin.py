@@ -84,11 +84,16 @@ def test_a_wrong_masking_term_would_be_caught(pto):
 # ---------------------------------------------------------------- (ii) converged Cornell pixels against a brute-force float64 tracer
 
 
-def numpy_radiance(sd, width, height, n_paths, max_depth, rr_start, rng, drop_cosine=False):
+def numpy_radiance(sd, width, height, n_paths, max_depth, rr_start, rng, drop_cosine=False, own_roulette=False, wrong=None):
     """Mean radiance and standard error per pixel of a width x height frame: float64, numpy RNG, brute-force intersection of every
-    triangle and sphere, Lambert surfaces only, implicit light hits only, depth cut and roulette as docs/SPEC.md §5 states them
-    (they are part of the expectation). `drop_cosine`: sample the hemisphere uniformly WITHOUT the 2 cos weight (a deliberately
-    wrong estimator, to show the comparison has teeth)."""
+    triangle and sphere, implicit light hits only, the depth cut of docs/SPEC.md §5 (it is part of the expectation).
+    Surfaces are evaluated from the physics, not with the spec's sampling routines: Lambert by cosine sampling in an own
+    parametrisation; rough metal by sampling the GGX normal distribution D(h) cos(theta_h) (Walter et al. 2007 — the spec and both
+    implementations use Heitz's visible-normal sampling) and weighting with BRDF * cos / pdf; mirror and glass by Snell / exact
+    unpolarised Fresnel. `own_roulette`: Russian roulette with a constant survival probability of 0.85 instead of the spec's
+    throughput-dependent one (any roulette leaves the expectation alone, so this checks the spec's for bias).
+    `drop_cosine`: sample the hemisphere uniformly WITHOUT the 2 cos weight; `wrong="no_masking"`: leave the Smith terms out of the
+    metal weight; `wrong="no_reflection"`: glass always refracts (deliberately wrong estimators, to show the comparisons have teeth)."""
     verts = np.asarray(sd.verts, np.float64).reshape(-1, 3, 3)
     v0, e1, e2 = verts[:, 0], verts[:, 1] - verts[:, 0], verts[:, 2] - verts[:, 0]
     tri_mat = np.asarray(sd.tri_mat)
@@ -96,7 +101,8 @@ def numpy_radiance(sd, width, height, n_paths, max_depth, rr_start, rng, drop_co
     sph_mat = np.asarray(sd.sph_mat)
     alb = np.asarray(sd.mats["albedo"], np.float64)
     emi = np.asarray(sd.mats["emission"], np.float64)
-    assert (np.asarray(sd.mats["kind"]) == 0).all()
+    kinds = np.asarray(sd.mats["kind"])
+    rough, ior = np.asarray(sd.mats["roughness"], np.float64), np.asarray(sd.mats["ior"], np.float64)
     cam = sd.cam
     org, fwd = np.array(cam.origin[:], np.float64), np.array(cam.forward[:], np.float64)
     right, up = np.array(cam.right[:], np.float64), np.array(cam.up[:], np.float64)
@@ -158,24 +164,72 @@ def numpy_radiance(sd, width, height, n_paths, max_depth, rr_start, rng, drop_co
                 if depth >= max_depth:
                     alive[idx] = False
                     break
-                # Lambert: direction on the hemisphere around nrm
-                u1, u2 = rng.random(idx.size), rng.random(idx.size)
-                if drop_cosine:
-                    cz = u1
-                else:
-                    cz = np.sqrt(u1)  # pdf cos/pi: the weight is the albedo
-                sz = np.sqrt(np.maximum(0.0, 1.0 - cz * cz))
+                m = idx.size
+                u1, u2, u3 = rng.random(m), rng.random(m), rng.random(m)
                 a = np.where(np.abs(nrm[:, 0:1]) > 0.5, np.array([[0.0, 1.0, 0.0]]), np.array([[1.0, 0.0, 0.0]]))
                 tx = np.cross(a, nrm); tx /= np.linalg.norm(tx, axis=1, keepdims=True)
                 ty = np.cross(nrm, tx)
-                wi = (sz * np.cos(2 * np.pi * u2))[:, None] * tx + (sz * np.sin(2 * np.pi * u2))[:, None] * ty + cz[:, None] * nrm
-                T[idx] *= alb[mat]
+                cosi = np.clip(-(dd * nrm).sum(1), 0.0, 1.0)
+                kd = kinds[mat]
+                wi = np.zeros((m, 3)); W = np.ones((m, 3)); side = np.ones(m); ok = np.ones(m, bool)
+                # ---- Lambert: cosine-weighted direction, weight = albedo
+                lam = kd == 0
+                cz = u1 if drop_cosine else np.sqrt(u1)
+                sz = np.sqrt(np.maximum(0.0, 1.0 - cz * cz))
+                wl = (sz * np.cos(2 * np.pi * u2))[:, None] * tx + (sz * np.sin(2 * np.pi * u2))[:, None] * ty + cz[:, None] * nrm
+                wi[lam] = wl[lam]; W[lam] = alb[mat][lam]
+                # ---- metal: Schlick Fresnel with the albedo as F0; mirror, or GGX with the separable Smith term
+                met = kd == 1
+                if met.any():
+                    al = rough[mat]
+                    mir = met & (al == 0.0)
+                    refl = dd + 2.0 * cosi[:, None] * nrm
+                    wi[mir] = refl[mir]
+                    W[mir] = (alb[mat] + (1.0 - alb[mat]) * ((1.0 - cosi) ** 5)[:, None])[mir]
+                    rgh = met & (al > 0.0)
+                    if rgh.any():
+                        al2 = np.where(rgh, al, 1.0) ** 2
+                        ch = np.sqrt((1.0 - u1) / (1.0 + (al2 - 1.0) * u1))  # cos(theta_h) ~ D(h) cos(theta_h)
+                        sh = np.sqrt(np.maximum(0.0, 1.0 - ch * ch))
+                        hv = (sh * np.cos(2 * np.pi * u2))[:, None] * tx + (sh * np.sin(2 * np.pi * u2))[:, None] * ty + ch[:, None] * nrm
+                        woh = -(dd * hv).sum(1)
+                        wr = 2.0 * woh[:, None] * hv + dd
+                        ci = (wr * nrm).sum(1)
+                        good = (woh > 0.0) & (ci > 0.0)
+                        aa = np.where(rgh, al, 1.0)
+                        g1o = 2.0 * cosi / (cosi + np.sqrt(aa * aa + (1.0 - aa * aa) * cosi * cosi) + 1e-300)
+                        g1i = 2.0 * ci / (ci + np.sqrt(aa * aa + (1.0 - aa * aa) * ci * ci) + 1e-300)
+                        fr = alb[mat] + (1.0 - alb[mat]) * ((1.0 - np.clip(woh, 0.0, 1.0)) ** 5)[:, None]
+                        gg = 1.0 if wrong == "no_masking" else g1o * g1i
+                        wgt = fr * (gg * woh / np.maximum(cosi * ch, 1e-300))[:, None]  # f cos_i / pdf, pdf = D cos_h / (4 wo.h)
+                        wi[rgh] = wr[rgh]; W[rgh] = wgt[rgh]
+                        ok &= ~(rgh & ~good)
+                # ---- glass: Snell + exact unpolarised Fresnel, the lobe chosen with probability F; weight = albedo
+                die = kd == 2
+                if die.any():
+                    n1 = np.where(flip, ior[mat], 1.0); n2 = np.where(flip, 1.0, ior[mat])  # flip: the ray is leaving the medium
+                    eta = n1 / n2
+                    s2 = eta * eta * (1.0 - cosi * cosi)
+                    tir = s2 >= 1.0
+                    ct = np.sqrt(np.maximum(0.0, 1.0 - s2))
+                    rs = (n1 * cosi - n2 * ct) / (n1 * cosi + n2 * ct + 1e-300)
+                    rp = (n2 * cosi - n1 * ct) / (n2 * cosi + n1 * ct + 1e-300)
+                    fres = np.where(tir, 1.0, 0.5 * (rs * rs + rp * rp))
+                    do_refl = (u3 < fres) if wrong != "no_reflection" else tir
+                    refl = dd + 2.0 * cosi[:, None] * nrm
+                    refr = eta[:, None] * dd + (eta * cosi - ct)[:, None] * nrm
+                    wd = np.where(do_refl[:, None], refl, refr)
+                    wi[die] = wd[die]; W[die] = alb[mat][die]
+                    side[die & ~do_refl] = -1.0
+                wi /= np.maximum(np.linalg.norm(wi, axis=1, keepdims=True), 1e-300)
+                alive[idx[~ok]] = False
+                T[idx] *= W
                 if depth >= rr_start:
-                    q = np.minimum(T[idx].max(1), 0.95)
-                    survive = rng.random(idx.size) < q
+                    q = np.full(m, 0.85) if own_roulette else np.minimum(T[idx].max(1), 0.95)
+                    survive = rng.random(m) < q
                     T[idx] /= np.where(q > 0, q, 1.0)[:, None]
                     alive[idx[~survive]] = False
-                o[idx] = oo + t_best[:, None] * dd + 1e-4 * nrm
+                o[idx] = oo + t_best[:, None] * dd + (side * 1e-4)[:, None] * nrm
                 d[idx] = wi
             means[y, x] = L.mean(0)
             errs[y, x] = L.std(0, ddof=1) / np.sqrt(n)
@@ -208,3 +262,55 @@ def test_a_missing_cosine_would_be_caught(P, pto):
     mean, err = numpy_radiance(sd, w, h, 16000, 8, 3, np.random.default_rng(1), drop_cosine=True)
     z = np.abs(ref[..., :3] - mean) / np.maximum(err * np.sqrt(1.0 + 16000 / 4096), 1e-6)
     assert (z * z).sum() > 48 + 15 * np.sqrt(2 * 48), (z * z).sum()  # chi-square: far outside what 48 honest values give
+
+
+def test_converged_glass_and_metal_pixels_match_an_independent_estimator(P, pto):
+    """BASELINE config C4's scene (Cornell + glass sphere, rough gold, mirror, Lambert) at max depth 16: the oracle's converged 4 x 4
+    frame against the float64 tracer that samples the GGX lobe by D(h) cos(theta_h) instead of visible normals, picks glass lobes
+    from its own Snell / Fresnel code and plays a different Russian roulette. Caustic paths make the per-pixel spread heavy-tailed,
+    hence the wider band than for the Lambert box: no channel beyond 5 combined sigma, at most 3 of 48 beyond 3."""
+    w = h = 4
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, w, h)
+    spp, n = 32768, 40000
+    ref, _ = pto.render(pto.Scene(sd), P.make_params(w, h, spp=spp, max_depth=16, rr_start=3, seed=4242))
+    mean, err = numpy_radiance(sd, w, h, n, 16, 3, np.random.default_rng(7), own_roulette=True)
+    sigma = np.sqrt(err ** 2 + (err * np.sqrt(n / spp)) ** 2)
+    z = np.abs(ref[..., :3] - mean) / np.maximum(sigma, 1e-6)
+    assert (z > 3.0).sum() <= 3 and z.max() < 5.0, (z.max(), (z > 3).sum())
+    assert (z * z).sum() < 48 + 6 * np.sqrt(2 * 48), (z * z).sum()
+
+
+def aim(sd, target, half_width):
+    """Point the scene's pinhole camera at `target` with a field of view of +-half_width (tangent) across the frame height."""
+    cam = sd.cam
+    o = np.array(cam.origin[:], np.float64)
+    f = np.asarray(target, np.float64) - o
+    f /= np.linalg.norm(f)
+    r = np.cross(f, [0.0, 1.0, 0.0]); r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    for k in range(3):
+        cam.forward[k] = f[k]; cam.right[k] = r[k] * half_width; cam.up[k] = -u[k] * half_width  # image row 0 is the top
+
+
+@pytest.mark.parametrize("what,target,half_width,wrong", [("glass sphere", (-0.45, -0.65, 0.25), 0.11, "no_reflection"),
+                                                         ("rough gold sphere", (0.5, -0.65, -0.3), 0.09, "no_masking")])
+def test_close_ups_of_the_specular_spheres(P, pto, what, target, half_width, wrong):
+    """The same comparison with the camera zoomed onto C4's glass sphere and onto its rough-metal sphere, so that those BSDFs fill
+    the 16 pixels: the honest independent estimator agrees with the oracle; one that never reflects at the glass surface /
+    leaves out the Smith masking term (gold roughened to alpha 0.6 for this close-up) does not."""
+    w = h = 4
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, w, h)
+    aim(sd, target, half_width)
+    if wrong == "no_masking":
+        sd.mats["roughness"][sd.mats["kind"] == 1] *= 4.0  # gold at alpha 0.6 (the mirror stays 0): where the Smith terms matter
+    spp, n = 16384, 24000
+    ref, _ = pto.render(pto.Scene(sd), P.make_params(w, h, spp=spp, max_depth=16, rr_start=3, seed=99))
+    for bad in (None, wrong):
+        mean, err = numpy_radiance(sd, w, h, n, 16, 3, np.random.default_rng(3), own_roulette=True, wrong=bad)
+        sigma = np.sqrt(err ** 2 + (err * np.sqrt(n / spp)) ** 2)
+        z = np.abs(ref[..., :3] - mean) / np.maximum(sigma, 1e-6)
+        chi2 = (z * z).sum()
+        if bad is None:
+            assert (z > 3.0).sum() <= 3 and z.max() < 5.0 and chi2 < 48 + 6 * np.sqrt(2 * 48), (what, z.max(), (z > 3).sum(), chi2)
+        else:
+            assert chi2 > 48 + 15 * np.sqrt(2 * 48), (what, bad, chi2)
