@@ -657,8 +657,8 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
             const bool use_packed = ext_choice == (uint32_t)EXT_PACKED || (probing && L.iters == 3u);
             const int kernel = use_packed ? EXT_PACKED : (ext_choice == (uint32_t)EXT_POOL && !split_kernels) ? EXT_POOL : EXT_SIMPLE;
             const bool compact = bucket_specular; // forced: buckets re-append, there are no fixed positions
-            // One kernel per iteration by default: the one-ray-per-lane k_extend shades its own hits (mode 0: Lambert-only
-            // scene, lean code; 2: all kinds). The lane-packing kernel and the bucketed pipeline keep k_shade as a second kernel.
+            // One kernel per iteration by default: every extend kernel (one ray per lane, lane-packing, pooled) shades its own hits
+            // (mode 0: Lambert-only scene, lean code; 2: all kinds). PT_FLAG_SPLIT_KERNELS / _BUCKET_SPECULAR run k_shade as a second kernel.
             const int shade_mode = s->has_specular ? 2 : 0;
             const bool fused = !split_kernels;
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
