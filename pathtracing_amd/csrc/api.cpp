@@ -35,11 +35,14 @@ uint32_t host_pcg(uint32_t x)
     return (w >> 22) ^ w;
 }
 
+thread_local uint64_t g_device_allocs = 0; // counts DevBuf allocations: a frame that had to allocate is a cold frame (its rate is not a measurement)
+
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
     hipError_t ensure(size_t count)
     {
         if (count <= n && p) return hipSuccess;
+        ++g_device_allocs;
         if (p) { (void)hipFree(p); p = nullptr; n = 0; }
         hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
         if (e == hipSuccess) n = count ? count : 1;
@@ -112,6 +115,7 @@ struct pt_scene {
     DevBuf<float4> d_nodes, d_tris, d_spheres, d_mats;
     bool has_specular = false;
     mutable uint32_t ext_choice = 0;     // cache, not scene content: the extend kernel an earlier frame's probe picked (0 = none yet, ExtendKernel otherwise)
+    mutable double rate_simple = 0.0, rate_packed = 0.0; // rays per ms of whole frames run on one kernel (frames too short to probe inside)
     DevBuf<uint32_t> d_sph_mat;
     DeviceScene ds{};
 };
@@ -438,7 +442,7 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     for (int k = 0; k < 3; ++k) d.sky[k] = s->sky[k];
     d.bvh_width = bvh_width;
     d.cam = s->cam;
-    s->ext_choice = 0;
+    s->ext_choice = 0; s->rate_simple = s->rate_packed = 0.0;
     s->has_specular = false;
     for (const pt_material &m : s->mats) if (m.kind != PT_LAMBERT) s->has_specular = true;
     s->committed = true;
@@ -562,6 +566,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     if (slots64 >= (1ull << 28)) return fail(c, PT_ERR_UNSUPPORTED, "frame too large: %llu slots (pixels of this rank x streams), limit 2^28", (unsigned long long)slots64); // kernels.hip at(): 32-bit byte offsets
     const uint32_t n_slots = (uint32_t)slots64;
 
+    const uint64_t allocs_before = g_device_allocs;
     HIP_TRY(c, c->ray_o.ensure(n_slots)); HIP_TRY(c, c->ray_d.ensure(n_slots)); HIP_TRY(c, c->thr.ensure(n_slots));
     HIP_TRY(c, c->acc.ensure(n_slots)); HIP_TRY(c, c->tiles.ensure(pixel_slots)); HIP_TRY(c, c->hit.ensure(n_slots)); HIP_TRY(c, c->sd.ensure(n_slots));
     // every queue = kShards regions of shard_cap entries; shard s owns the 256-slot groups g with g % kShards == s
@@ -611,7 +616,18 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     // one loop. Inside a loop a shard's queue can only shrink (slots die, none are born), so the queue sizes read back
     // kLag iterations ago are valid launch bounds: the host never stalls the GPU to size a grid.
     // per-kernel timing, visit counting and the extend-kernel probe (events around single iterations) want kernels alone on the GPU
-    const bool will_probe = forced_choice == 0u && s->ext_choice == 0u;
+    // Which extend kernel (when no flag forces one): measured, per scene, and remembered in the scene.
+    //   inside a frame : iteration 2 of group 0 runs the one-ray-per-lane kernel, iteration 3 the lane-packing one (bit-identical
+    //                    results), each bracketed by events; accepted only if both traced a real share of the frame's slots;
+    //   across frames  : a frame too short for that (few samples per stream: it is over in two iterations) runs whole on one
+    //                    kernel — the first on the one-ray-per-lane kernel, the next on the lane-packing one — and the rays per
+    //                    millisecond of the two frames decide.
+    // The faster per ray wins (packed needs +10 %). Deep incoherent traversals (1M-triangle soup) gain ~2.5x from packing, shallow
+    // ones (walls of a box) lose ~35 %, and no static property of the tree tells them apart. Counting / profiling
+    // frames neither probe nor feed the decision: their kernels are instrumented builds.
+    const bool undecided = forced_choice == 0u && s->ext_choice == 0u && !count && !profile;
+    const uint32_t frame_kernel = (undecided && s->rate_simple > 0.0 && s->rate_packed == 0.0) ? (uint32_t)EXT_PACKED : (uint32_t)EXT_SIMPLE;
+    const bool will_probe = undecided && frame_kernel == (uint32_t)EXT_SIMPLE;
     const uint32_t n_loops = (profile || count || will_probe) ? 1u : c->groups ? c->groups : (n_slots <= kTwoLoopsBelow ? 2u : 1u);
     const uint32_t per_group = kShards / n_loops;
     //
@@ -630,11 +646,9 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     const uint64_t max_iters = (uint64_t)p->spp * p->max_depth + kLag + 2;
     size_t nev = 0;
     uint32_t iters_max = 0;
-    // Which extend kernel: forced by a flag, remembered from an earlier frame of this scene, or probed now — iteration 2
-    // of group 0 runs the one-ray-per-lane kernel, iteration 3 the lane-packing one (bit-identical results), each
-    // bracketed by events; the faster per ray wins for the rest of the frame and for later frames. Deep incoherent
-    // traversals (1M-triangle soup) gain ~1.5x from packing, shallow ones (walls of a box) lose ~8 %, and nothing static tells them apart.
-    uint32_t ext_choice = forced_choice ? forced_choice : s->ext_choice; // 0 = still probing, else ExtendKernel
+    // 0 = probing inside this frame, else the ExtendKernel every iteration uses
+    uint32_t ext_choice = forced_choice ? forced_choice : s->ext_choice ? s->ext_choice : will_probe ? 0u : frame_kernel;
+    bool mixed = false; // this frame ran probe iterations on both kernels: its overall rate says nothing about either
     uint64_t probe_n[2] = { 0, 0 }, slot_launches = 0;
     const bool trace = profile && getenv("PTRT_TRACE") != nullptr; // developer aid: per-iteration table on stderr
     std::vector<uint64_t> trace_alive, trace_rays;
@@ -706,8 +720,14 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
                     HIP_TRY(c, hipEventElapsedTime(&ms_simple, c->ev_probe[0], c->ev_probe[1]));
                     HIP_TRY(c, hipEventElapsedTime(&ms_packed, c->ev_probe[2], c->ev_probe[3]));
                     const double r_simple = probe_n[0] / std::max((double)ms_simple, 1e-6), r_packed = probe_n[1] / std::max((double)ms_packed, 1e-6);
-                    ext_choice = (probe_n[0] && probe_n[1] && r_packed > 1.10 * r_simple) ? 2u : 1u;
-                    s->ext_choice = ext_choice;
+                    const uint64_t enough = (uint64_t)(n_slots / n_loops) / 8u; // each probe iteration must have traced a real share of the slots
+                    if (probe_n[0] >= enough && probe_n[1] >= enough) {
+                        ext_choice = r_packed > 1.10 * r_simple ? (uint32_t)EXT_PACKED : (uint32_t)EXT_SIMPLE;
+                        s->ext_choice = ext_choice;
+                    } else { // inconclusive (the frame was all but over): finish on the default and let whole frames decide
+                        ext_choice = (uint32_t)EXT_SIMPLE;
+                        mixed = probe_n[1] >= enough / 8u; // did the lane-packing iteration trace enough to colour this frame's rate?
+                    }
                 }
             }
         }
@@ -739,7 +759,12 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     // of them came after the wave's first leaf phase of the ray (diagnostic for tools/exp_util.py)
     out.reserved[3] = (u64_at(kCntWaveNodeIters) & 0xFFFFFFFFFFull) | (u64_at(kCntWaveNodeIters + 2) << 40);
     out.iterations = iters; out.extend_launches = iters;
-    out.reserved[0] = ext_choice; // extend kernel in use at frame end: 1 = one ray per lane, 2 = lane-packing, 0 = frame too short to probe
+    const bool cold_frame = g_device_allocs != allocs_before; // first touch of fresh allocations: 30 % slower, not a measurement
+    if (undecided && s->ext_choice == 0u && !mixed && !cold_frame && out.rays >= (1u << 20) && out.gpu_ms > 0.0) { // a whole frame on one kernel: remember its rate
+        (frame_kernel == (uint32_t)EXT_PACKED ? s->rate_packed : s->rate_simple) = (double)out.rays / out.gpu_ms;
+        if (s->rate_simple > 0.0 && s->rate_packed > 0.0) s->ext_choice = s->rate_packed > 1.10 * s->rate_simple ? (uint32_t)EXT_PACKED : (uint32_t)EXT_SIMPLE;
+    }
+    out.reserved[0] = ext_choice ? ext_choice : (uint32_t)EXT_SIMPLE; // extend kernel in use at frame end (ExtendKernel)
     out.reserved[1] = hc[kCntCompactions]; // (shard, iteration) pairs that re-packed their queue (the others carried it over in place)
     {   // paths = owned in-image pixels x spp
         uint64_t px = 0;

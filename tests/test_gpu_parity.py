@@ -162,6 +162,27 @@ def test_headline_configuration_as_benchmarked(P, pto, renderer):
     assert st2.rays == st.rays and np.array_equal(renderer.ReadFramebuffer(), ref)
 
 
+def test_c2_and_c3_as_benchmarked(P, pto, renderer):
+    """BASELINE configs[1] exactly (Cornell, 1920x1080, 64 spp, 8 streams) and configs[2] (1M-triangle soup, 1920x1080, 8 streams) at
+    16 of its 64 spp, default layout and probed extend kernel (the soup ends up on the lane-packing kernel): frames bit-identical to
+    the oracle, ray counts equal."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL, 0, 0x5EED0001, 1920, 1080)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(1920, 1080, spp=64, max_depth=8, streams=8), 0)
+    assert_parity(img, st, ref, ost)
+    sd = P.make_scene(P.native.PT_SCENE_TRIANGLE_SOUP, 1 << 20, 0x5EED0001, 1920, 1080)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(1920, 1080, spp=16, max_depth=8, streams=8), 0)
+    assert_parity(img, st, ref, ost)
+    # 2 samples per stream: the frame is over before the in-frame probe can compare anything, so whole frames decide — the first ran
+    # on the one-ray-per-lane kernel, the second runs on the lane-packing one, the third on the winner (here: lane-packing)
+    # (a frame that had to allocate its buffers is not counted as a measurement, hence one or two frames on kernel 1 first)
+    kernels = [int(st.reserved[0])]
+    for _ in range(3):
+        st2 = renderer.Render(0.0)
+        kernels.append(int(st2.reserved[0]))
+        assert st2.rays == ost.rays and np.array_equal(renderer.ReadFramebuffer(), ref)
+    assert kernels in ([1, 2, 2, 2], [1, 1, 2, 2]), kernels
+
+
 def test_c4_at_its_real_depth_and_spp(P, pto, renderer):
     """BASELINE configs[3] (Cornell + glass + rough metal) at its real 256 spp and max depth 16, on a 480x270 frame."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, 480, 270)
