@@ -75,6 +75,23 @@ public unsafe class HipRenderer : IDisposable
         return px;
     }
 
+    public byte[] ReadFramebufferSrgb8() // what the reference's B8G8R8A8Srgb swapchain shows of that image (SwapChain.cs:157-158)
+    {
+        byte[] px = new byte[(ulong)Width * Height * 4];
+        fixed (byte* p = px) Ptrt.Check(Ptrt.pt_framebuffer_read_srgb8(_ctx, p, (ulong)px.Length), _ctx);
+        return px;
+    }
+
+    // scheduling knobs (none changes a pixel): read, modify, write back
+    public PtTuning Tuning
+    {
+        get { PtTuning t; Ptrt.Check(Ptrt.pt_context_get_tuning(_ctx, &t), _ctx); return t; }
+        set { Ptrt.Check(Ptrt.pt_context_set_tuning(_ctx, &value), _ctx); }
+    }
+
+    internal void* Context => _ctx;
+    internal void* Scene => _scene;
+
     protected virtual void Dispose(bool disposing)
     {
         if (_disposed) return;
@@ -84,4 +101,51 @@ public unsafe class HipRenderer : IDisposable
     }
     public void Dispose() { Dispose(true); GC.SuppressFinalize(this); }
     ~HipRenderer() { Dispose(false); }
+}
+
+// One frame over several GPUs of the node (include/ptrt.h pt_comm): a HipRenderer per device, the same scene on each, tiles dealt
+// round-robin, one ncclGather per frame inside libptrt. The reference is single-device (GraphicsDevice.cs:176-183); this is what stands
+// above its Renderer when the node has 8 GPUs. NOT compiled here (no dotnet in the image).
+public unsafe class HipMultiRenderer : IDisposable
+{
+    private readonly HipRenderer[] _r;
+    private void* _comm;
+    public PtRenderParams Params;
+    public PtStats[] LastStats;
+
+    public HipMultiRenderer(int gpus, uint width = 1920, uint height = 1080)
+    {
+        _r = new HipRenderer[gpus];
+        for (int i = 0; i < gpus; i++) { _r[i] = new HipRenderer(width, height); _r[i].Init(i); }
+        Params = _r[0].Params;
+        LastStats = new PtStats[gpus];
+    }
+
+    public void LoadSyntheticScene(PtSceneKind kind, uint detail = 0)
+    {
+        foreach (HipRenderer r in _r) r.LoadSyntheticScene(kind, detail); // replicated scene
+        Params.mode = (uint)PtMode.PathTrace;
+        void** ctxs = stackalloc void*[_r.Length];
+        for (int i = 0; i < _r.Length; i++) ctxs[i] = _r[i].Context;
+        if (_comm != null) Ptrt.pt_comm_destroy(_comm);
+        void* c; Ptrt.Check(Ptrt.pt_comm_create(ctxs, (uint)_r.Length, 0, 0, &c)); _comm = c;
+    }
+
+    public void Render(float delta)
+    {
+        void** scenes = stackalloc void*[_r.Length];
+        for (int i = 0; i < _r.Length; i++) scenes[i] = _r[i].Scene;
+        fixed (PtRenderParams* p = &Params) fixed (PtStats* st = LastStats)
+            Ptrt.Check(Ptrt.pt_comm_render(_comm, scenes, p, st), _r[0].Context);
+    }
+
+    public HipRenderer Root => _r[0]; // holds the assembled frame
+
+    public void Dispose()
+    {
+        if (_comm != null) Ptrt.pt_comm_destroy(_comm);
+        _comm = null;
+        foreach (HipRenderer r in _r) r.Dispose();
+        GC.SuppressFinalize(this);
+    }
 }
