@@ -758,6 +758,11 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     // PT_FLAG_COUNT_VISITS + one-ray-per-lane kernel: wave-level node-loop iterations (bits 0-39) and, from bit 40 up, how many
     // of them came after the wave's first leaf phase of the ray (diagnostic for tools/exp_util.py)
     out.reserved[3] = (u64_at(kCntWaveNodeIters) & 0xFFFFFFFFFFull) | (u64_at(kCntWaveNodeIters + 2) << 40);
+    if (count && getenv("PTRT_TRACE")) { // developer aid: where the node loop's lane-slots go (one-ray-per-lane kernel)
+        const double slots = 64.0 * (double)u64_at(kCntWaveNodeIters), v = (double)out.node_visits, lf = (double)u64_at(kCntIdleLeaf), dn = (double)u64_at(kCntIdleDone);
+        if (slots > 0) fprintf(stderr, "ptrt: node-loop lane-slots %.3g: visiting %.1f %%, waiting at a leaf %.1f %%, ray finished %.1f %%, no ray %.1f %%\n", slots,
+                               100 * v / slots, 100 * lf / slots, 100 * dn / slots, 100 * (slots - v - lf - dn) / slots);
+    }
     out.iterations = iters; out.extend_launches = iters;
     const bool cold_frame = g_device_allocs != allocs_before; // first touch of fresh allocations: 30 % slower, not a measurement
     if (undecided && s->ext_choice == 0u && !mixed && !cold_frame && out.rays >= (1u << 20) && out.gpu_ms > 0.0) { // a whole frame on one kernel: remember its rate

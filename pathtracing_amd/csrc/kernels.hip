@@ -603,7 +603,8 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     const bool active = slot != kInvalidSlot;                  // holes: paths that ended since the queue was last compacted
     const StackCtx stk{ s_stack, kExtBlock, tid, qbase + gid };
 
-    unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0, c_wave_iters = 0, c_wave_iters_late = 0;
+    unsigned long long c_nodes = 0, c_tris = 0, c_sph = 0, c_wave_iters = 0, c_wave_iters_late = 0, c_idle_leaf = 0, c_idle_done = 0;
+    __shared__ int32_t s_state[COUNT ? 64 : 1]; // COUNT diagnostics: every lane's `cur` (1 = no ray), readable by the lane that counts
     PathRegs r;
     r.o = v3(0.f, 0.f, 0.f); r.d = v3(0.f, 0.f, 1.f); r.T = v3(0.f, 0.f, 0.f); r.key = r.sample = r.depth = 0u;
     if (active) {
@@ -617,6 +618,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     const uint64_t alive_mask = __ballot(alive);
     if (alive_mask == 0) break;
     wave_rays += (uint32_t)__popcll(alive_mask);
+    if (COUNT && kExtBlock == 64u) { s_state[tid] = alive ? 0 : 1; __syncthreads(); } // 1: neither a node, a leaf nor PT_BVH_EMPTY
     if (alive) {
         const V3 o = r.o, d = r.d;
         Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
@@ -648,14 +650,21 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
                 if (++steps > (1u << 22)) { atomicOr(&cold().ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; break; }
                 if (COUNT) { // one lane per wave-iteration counts it; [1]: iterations after the wave's first leaf phase of this ray
                     c_nodes++;
-                    if (lane_id() == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) { c_wave_iters++; if (late_cycle) c_wave_iters_late++; }
+                    if (lane_id() == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) {
+                        c_wave_iters++; if (late_cycle) c_wave_iters_late++;
+                        // why the other lanes of this iteration are idle (their state sits in LDS: they are masked off here)
+                        uint32_t n_leaf = 0, n_done = 0;
+                        for (uint32_t l = 0; l < 64u; ++l) { const int32_t c2 = s_state[l]; n_leaf += c2 < 0 ? 1u : 0u; n_done += c2 == PT_BVH_EMPTY ? 1u : 0u; }
+                        c_idle_leaf += n_leaf; c_idle_done += n_done;
+                    }
                 }
                 node_step<L>(nodes, stk, rs, h.t, cur, sp);
+                if (COUNT) s_state[tid & 63u] = cur;
             }
             if (cur == PT_BVH_EMPTY) break;
             if (COUNT) late_cycle = true;
             const uint32_t nt = leaf_step(tris, stk, o, d, h, cur, sp); // ---- leaf phase
-            if (COUNT) c_tris += nt;
+            if (COUNT) { c_tris += nt; s_state[tid & 63u] = cur; }
         }
 
         if (FUSE == SHADE_NONE) at(cold().ps.hit, slot) = make_float2(h.t, __uint_as_float(h.ref)); // k_shade walks the same queue in the same order
@@ -674,6 +683,8 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     if (COUNT && active) {
         if (c_wave_iters) atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntWaveNodeIters), c_wave_iters);
         if (c_wave_iters_late) atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntWaveNodeIters + 2), c_wave_iters_late);
+        if (c_idle_leaf) atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntIdleLeaf), c_idle_leaf);
+        if (c_idle_done) atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntIdleDone), c_idle_done);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntNodes), c_nodes);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntTris), c_tris);
         atomicAdd(reinterpret_cast<unsigned long long *>(ps.counters + kCntSph), c_sph);

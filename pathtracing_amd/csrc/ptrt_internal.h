@@ -45,7 +45,10 @@ constexpr uint32_t kCntError = kCntGlobals + 0;
 constexpr uint32_t kCntNodes = kCntGlobals + 2, kCntTris = kCntGlobals + 4, kCntSph = kCntGlobals + 6; // u64 each
 constexpr uint32_t kCntCompactions = kCntGlobals + 8; // (shard, iteration) pairs that re-packed their queue
 constexpr uint32_t kCntWaveNodeIters = kCntGlobals + 10; // u64, PT_FLAG_COUNT_VISITS: iterations of the wave-level node loop of k_extend
-constexpr uint32_t kCntTotalWords = kCntGlobals + 16;
+// u64 x 3, PT_FLAG_COUNT_VISITS, one-ray-per-lane kernel: lane-slots of the node loop spent (a) waiting at a leaf for the wave's node loop,
+// (b) with the ray already finished, (c) without a ray at all (hole, ended stream); the rest of 64 x iterations made a node visit
+constexpr uint32_t kCntIdleLeaf = kCntGlobals + 16, kCntIdleDone = kCntGlobals + 18, kCntIdleDead = kCntGlobals + 20;
+constexpr uint32_t kCntTotalWords = kCntGlobals + 24;
 
 // An extend queue has LEN entries of which ALIVE hold a slot; the rest are kInvalidSlot holes left by paths that ended
 // while the queue was carried over in place (k_shade, compact == 0). Both counts share the shard's 64-B line.
