@@ -239,7 +239,7 @@ void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint3
 //   bottom : inside a cluster the device's topology and boxes are kept; subtrees of at most kMaxLeaf triangles become leaves unless
 //            splitting them lowers the SAH cost — the leaf rule of Builder::build (their triangles are contiguous in Morton order).
 #ifndef PT_LBVH_CLUSTER
-#define PT_LBVH_CLUSTER 256
+#define PT_LBVH_CLUSTER 128
 #endif
 constexpr uint32_t kClusterTris = PT_LBVH_CLUSTER; // 0: no SAH storey, the LBVH as it is
 void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out)
