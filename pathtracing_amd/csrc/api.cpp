@@ -41,7 +41,7 @@ template <typename T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
     hipError_t ensure(size_t count)
     {
-        if (count <= n && p) return hipSuccess;
+        if (p && count <= n && (n <= (1u << 20) || count >= n / 4)) return hipSuccess; // big enough, and not more than 4x too big
         ++g_device_allocs;
         if (p) { (void)hipFree(p); p = nullptr; n = 0; }
         hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));

@@ -183,6 +183,20 @@ def test_c2_and_c3_as_benchmarked(P, pto, renderer):
     assert kernels in ([1, 2, 2, 2], [1, 1, 2, 2]), kernels
 
 
+def test_largest_slot_space(P, pto, renderer):
+    """The largest frame the kernels' 32-bit slot offsets allow (2^28 slots = pixels x streams): 3840x2160 with 32 sample streams is
+    265 M slots (a 4.2 GB float4 array: byte offsets just below 2^32). One sample per stream, depth 4, against the oracle; one stream
+    more is refused."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_TESS, 200000, 0x5EED0001, 3840, 2160)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(3840, 2160, spp=32, max_depth=4, streams=32), 0)
+    assert_parity(img, st, ref, ost)
+    renderer.Params = P.make_params(3840, 2160, spp=33, max_depth=4, streams=33)
+    with pytest.raises(P.PtException, match="too large"):
+        renderer.Render(0.0)
+    renderer.Params = P.make_params(64, 64, spp=1)  # a small frame gives the 20 GB of path state back (buffers shrink when 4x too big)
+    renderer.Render(0.0)
+
+
 def test_c4_at_its_real_depth_and_spp(P, pto, renderer):
     """BASELINE configs[3] (Cornell + glass + rough metal) at its real 256 spp and max depth 16, on a 480x270 frame."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, 480, 270)
