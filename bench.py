@@ -249,7 +249,8 @@ def roofline(P, r, mk, args, info, kernel_choice, W, H):
               "records_per_ray": round(n_nodes_ray + n_tris_ray, 2)}
     exe = os.path.join(ROOT, "tools", "ubench", "gather_tree")
     if os.path.exists(exe):
-        levels, tris = max(1, round(n_nodes_ray)), max(0, round(n_tris_ray))
+        # a ray cannot descend further than the tree is deep: visits beyond that are returns to (warm) siblings, not new cold levels
+        levels, tris = max(1, min(round(n_nodes_ray), int(info.max_depth) - 1)), max(0, round(n_tris_ray))
         try:
             o = subprocess.run([exe, str(levels), f"{info.node_bytes / 1e6:.1f}", str(tris), f"{info.n_tris * 64 / 1e6:.1f}"], capture_output=True,
                                text=True, timeout=60).stdout.strip().splitlines()[-1]
