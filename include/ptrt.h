@@ -154,10 +154,12 @@ typedef struct {
                                frames of at most 12 M slots (a rank's share), else one */
     uint32_t finish_below;  /* a shard with at most this many live paths runs them to their end in one launch (default 4096; 0 = never) */
     uint32_t packed_chunk;  /* queue entries per wavefront of the lane-packing kernel, >= 64; 0 (default) = 256 with >= 4 streams, else 128 */
-    float compact_below;    /* a shard re-packs its queue in an iteration that starts with alive < this * length (default 0.9; > 1 every
-                               iteration; 0 never) */
+    float compact_below;    /* a shard re-packs its queue in a launch that would otherwise leave alive < this * length behind (default 0.9;
+                               > 1 every launch; 0 never) */
     float sparse_below;     /* one-ray-per-lane kernel: a launch that starts with alive < this * length advances one vertex only (default 0 = off) */
-    uint32_t reserved[2];
+    uint32_t sticky_samples; /* frames with at most this many samples per stream (spp / streams): a shard that has re-packed once re-packs
+                               in every launch, and with at most 2 samples per stream every launch re-packs (default 32; 0 = off) */
+    uint32_t reserved;
 } pt_tuning; /* 32 B */
 
 /* ---- context: replaces GraphicsDevice.Init (GraphicsDevice.cs:38-43) + Renderer.CreateResources (Renderer.cs:105-196) */

@@ -79,10 +79,13 @@ struct pt_context {
     uint32_t bounces = 0;                       // pt_tuning.bounces (1..64): path vertices per launch of the fused kernel (state in registers);
                                                 // 0 = max_depth / 2 clamped to [4, 8] (measured: depth 8 -> 4 is best, 12.9 vs 12.3 Grays/s at 8;
                                                 // depth 16 with glass -> 8 is best, 23.0 vs 20.6 at 4)
-    double compact_below = 0.9;                // pt_tuning.compact_below: a shard re-packs its queue in an iteration that starts with
-                                                // alive/length below this (>1 = every iteration, 0 = never); else carried in place.
-                                                // Measured (1M-tri Cornell): 1080p/64spp 0.75: 10786, 0.9: 11190, always: 11354 Mrays/s;
-                                                // 4K/1024spp 0.9: 12471, always: 11430 — re-packing mixes wavefronts, long frames feel it
+    double compact_below = 0.9;                // pt_tuning.compact_below: a shard re-packs its queue in a launch that would leave alive/length
+                                                // below this (>1 = every launch, 0 = never); else carried in place (want_compact, kernels.hip).
+    uint32_t sticky_samples = 32;               // pt_tuning.sticky_samples. Measured, 1M-tri Cornell 1080p, ms per frame by spp (8 streams),
+                                                // start-of-launch ratio (round 1) / predicted ratio / sticky / every launch:
+                                                //   8: 4.13/4.20/4.07/3.01  32: 10.95/10.93/9.70/9.61  64: 19.28/18.82/18.45/18.36
+                                                //   128: 38.15/36.12/36.04/36.06  256: 73.06/71.95/71.99/72.15  512: 142.8/141.5/143.0/143.7
+                                                //   1024: 284.5/283.7/289.9/292.5; 4K/1024: 1067.7/1064.1/1097.0/1108 (tools/exp_compact.py)
     double sparse_below = 0.0;                  // pt_tuning.sparse_below (0 = off, the default: measured ±0): see PathState::sparse_below
     uint32_t finish_below = 4096;             // pt_tuning.finish_below: a shard with no more alive paths than this runs them to
                                                 // their end in one launch of the fused kernel (0 = never)
@@ -226,7 +229,7 @@ pt_status pt_context_get_tuning(const pt_context *c, pt_tuning *o)
     if (!c || !o) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "pt_context_get_tuning: NULL argument");
     std::memset(o, 0, sizeof *o);
     o->bounces = c->bounces; o->loops = c->groups; o->finish_below = c->finish_below; o->packed_chunk = c->packed_chunk;
-    o->compact_below = (float)c->compact_below; o->sparse_below = (float)c->sparse_below;
+    o->compact_below = (float)c->compact_below; o->sparse_below = (float)c->sparse_below; o->sticky_samples = c->sticky_samples;
     return PT_OK;
 }
 
@@ -239,7 +242,7 @@ pt_status pt_context_set_tuning(pt_context *c, const pt_tuning *t)
     if (!(t->compact_below >= 0.f && t->compact_below <= 2.f) || !(t->sparse_below >= 0.f && t->sparse_below <= 1.f))
         return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: compact_below must be in [0,2], sparse_below in [0,1]");
     c->bounces = t->bounces; c->groups = t->loops; c->finish_below = t->finish_below; c->packed_chunk = t->packed_chunk;
-    c->compact_below = t->compact_below; c->sparse_below = t->sparse_below;
+    c->compact_below = t->compact_below; c->sparse_below = t->sparse_below; c->sticky_samples = t->sticky_samples;
     return PT_OK;
 }
 
@@ -585,6 +588,9 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     ps.counters = c->counters.p; ps.stack_ovf = c->stack_ovf.p; ps.stack_ovf_entries = ovf; ps.n_slots = n_slots; ps.shard_cap = shard_cap;
     ps.shard_base = 0; ps.shard_count = kShards;
     ps.compact_below = (float)c->compact_below; ps.finish_below = c->finish_below; ps.sparse_below = (float)c->sparse_below;
+    const uint32_t samples_per_stream = (p->spp + (p->streams ? p->streams : 1u) - 1u) / (p->streams ? p->streams : 1u);
+    ps.repack_sticky = (samples_per_stream <= c->sticky_samples && c->compact_below > 0.0) ? 1u : 0u;
+    const bool repack_always = ps.repack_sticky && samples_per_stream <= 2u; // nothing (or next to nothing) regenerates: every launch leaves holes
 
     FrameParams fp{};
     fp.width = p->width; fp.height = p->height; fp.spp = p->spp; fp.max_depth = p->max_depth; fp.rr_start = p->rr_start;
@@ -670,7 +676,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
             const bool probing = g == 0u && ext_choice == 0u && (L.iters == 2u || L.iters == 3u);
             const bool use_packed = ext_choice == (uint32_t)EXT_PACKED || (probing && L.iters == 3u);
             const int kernel = use_packed ? EXT_PACKED : (ext_choice == (uint32_t)EXT_POOL && !split_kernels) ? EXT_POOL : EXT_SIMPLE;
-            const bool compact = bucket_specular; // forced: buckets re-append, there are no fixed positions
+            const bool compact = bucket_specular || repack_always; // forced: buckets re-append, there are no fixed positions
             // One kernel per iteration by default: every extend kernel (one ray per lane, lane-packing, pooled) shades its own hits
             // (mode 0: Lambert-only scene, lean code; 2: all kinds). PT_FLAG_SPLIT_KERNELS / _BUCKET_SPECULAR run k_shade as a second kernel.
             const int shade_mode = s->has_specular ? 2 : 0;

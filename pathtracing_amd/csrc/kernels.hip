@@ -441,9 +441,19 @@ PT_DEV void fold_traced(const PathState &ps, uint32_t shard, uint32_t it)
 }
 
 // Queue policy, from the shard's own counters so that every workgroup of a launch decides the same and without host lag.
-PT_DEV bool want_compact(const PathState &ps, uint32_t len, uint32_t n_alive, bool forced)
+PT_DEV bool want_compact(const PathState &ps, uint32_t len, uint32_t n_alive, uint32_t prev_alive, bool sticky, bool forced)
 {
-    return forced || (float)n_alive < ps.compact_below * (float)len;
+    // A re-pack costs nothing in the launch that does it (tools/exp_compact.py: the returning atomic alone is unmeasurable) but
+    // it permutes the shard's wavefronts by arrival order, and every further one permutes them again: consecutive wavefronts
+    // stop being the streams of neighbouring pixel blocks and their node fetches stop sharing cache lines (+3..5 % ns per ray
+    // after ~100 re-packs with NO path lost). A hole costs a lane for every vertex of the next launch. So:
+    //   predicted : re-pack when the queue this launch leaves behind would be emptier than compact_below, counting the holes
+    //               it starts with plus as many deaths as the previous launch had (prev_alive - n_alive);
+    //   sticky    : (frames of few samples per stream, where all streams run dry within a launch or two and no history
+    //               predicts it) once a shard has re-packed - its queue is shorter than k_generate's - every launch does.
+    const uint32_t deaths = prev_alive > n_alive ? prev_alive - n_alive : 0u;
+    const uint32_t predicted = n_alive > deaths ? n_alive - deaths : 0u;
+    return forced || (sticky && len < ps.shard_cap) || (float)predicted < ps.compact_below * (float)len;
 }
 
 PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint32_t *q_next, uint32_t gid, uint32_t total, bool alive,
@@ -578,8 +588,9 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     {
         const PathState &ps = cold().ps;
         n = ps.counters[cnt_ext_index(ccur, shard)]; n_alive = ps.counters[cnt_alive_index(ccur, shard)];
-        do_compact = FUSE != SHADE_NONE && want_compact(ps, n, n_alive, a.compact != 0u);
+        do_compact = FUSE != SHADE_NONE && want_compact(ps, n, n_alive, ps.counters[cnt_prev_alive_index(ccur, shard)], ps.repack_sticky != 0u, a.compact != 0u);
         if (gid == 0) {
+            ps.counters[cnt_prev_alive_index(cnext, shard)] = n_alive;
             ps.counters[cnt_ext_index(czero, shard)] = 0u;         // the queue after next
             ps.counters[cnt_alive_index(czero, shard)] = 0u;
             fold_traced(ps, shard, it);
@@ -733,8 +744,9 @@ k_extend_packed(ExtArgs a)
     block_pos(a.ps, shard, bx, nbx);
     const uint32_t n = cold().ps.counters[cnt_ext_index(ccur, shard)], n_alive = cold().ps.counters[cnt_alive_index(ccur, shard)];
     const uint32_t lane = threadIdx.x;
-    const bool do_compact = FUSE != SHADE_NONE && want_compact(cold().ps, n, n_alive, compact != 0u);
+    const bool do_compact = FUSE != SHADE_NONE && want_compact(cold().ps, n, n_alive, 0u, false, compact != 0u); // holes cost this kernel one skipped pull: plain ratio
     if (bx == 0 && lane == 0) {
+        cold().ps.counters[cnt_prev_alive_index(cnext, shard)] = n_alive; // for a one-ray-per-lane launch that may follow (probe frames)
         cold().ps.counters[cnt_ext_index(czero, shard)] = 0u;
         cold().ps.counters[cnt_alive_index(czero, shard)] = 0u;
         fold_traced(cold().ps, shard, it);
@@ -955,8 +967,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_POOL
     {
         const PathState &ps = cold().ps;
         n = ps.counters[cnt_ext_index(ccur, shard)]; n_alive = ps.counters[cnt_alive_index(ccur, shard)];
-        do_compact = want_compact(ps, n, n_alive, a.compact != 0u);
+        do_compact = want_compact(ps, n, n_alive, ps.counters[cnt_prev_alive_index(ccur, shard)], ps.repack_sticky != 0u, a.compact != 0u);
         if (bx == 0 && lane == 0) {
+            ps.counters[cnt_prev_alive_index(cnext, shard)] = n_alive;
             ps.counters[cnt_ext_index(czero, shard)] = 0u;
             ps.counters[cnt_alive_index(czero, shard)] = 0u;
             fold_traced(ps, shard, it);
@@ -1124,7 +1137,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene sc, PathState ps, 
             ps.counters[cnt_bucket_index(parity ^ 1u, B_METAL + threadIdx.x, shard)] = 0u;
     } else total = ps.counters[cnt_ext_index(ccur, shard)];
     const uint32_t n_alive = ps.counters[cnt_alive_index(ccur, shard)];
-    const bool do_compact = SPEC || want_compact(ps, total, n_alive, compact != 0u);
+    const bool do_compact = SPEC || want_compact(ps, total, n_alive, 0u, false, compact != 0u);
     if (!SPEC && do_compact && n_alive && bx == 0 && threadIdx.x == 0) atomicAdd(&ps.counters[kCntCompactions], 1u);
     // SPEC: a small fixed grid strides over the (usually short, unknown-length) specular buckets, so an empty bucket
     // costs a few hundred trivial blocks instead of one per 256 queue slots. !SPEC: exactly one pass, grid sized by the host.

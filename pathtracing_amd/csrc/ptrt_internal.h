@@ -56,6 +56,8 @@ constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
 inline __host__ __device__ uint32_t cnt_ext_index(uint32_t parity, uint32_t shard) { return kCntExt + (parity * kShards + shard) * kCounterStride; }
 inline __host__ __device__ uint32_t cnt_alive_index(uint32_t parity, uint32_t shard) { return cnt_ext_index(parity, shard) + 1u; }
 // third word of the line: rays traced by the iteration that FILLED this queue; the next iteration folds it into rays[shard]
+// word 4 of the line: alive entries at the start of the launch that FILLED this queue (written by that launch's first thread)
+inline __host__ __device__ uint32_t cnt_prev_alive_index(uint32_t parity, uint32_t shard) { return cnt_ext_index(parity, shard) + 4u; }
 inline __host__ __device__ uint32_t cnt_traced_index(uint32_t parity, uint32_t shard) { return cnt_ext_index(parity, shard) + 2u; }
 inline __host__ __device__ uint32_t cnt_bucket_index(uint32_t parity, uint32_t bucket, uint32_t shard)
 {
@@ -93,7 +95,8 @@ struct PathState {           // SoA over slots
     uint32_t shard_base, shard_count; // the shards this launch covers: shard_base .. + shard_count (groups of shards run as
                                       // independent wavefront loops on their own streams, see api.cpp)
     // queue policy, decided on the device from the shard's own counters (no host lag):
-    float compact_below;     // re-pack a shard's queue when alive < compact_below * length (> 1: always, 0: never)
+    float compact_below;     // re-pack a shard's queue when the alive/length ratio it would leave is below this (> 1: always, 0: never)
+    uint32_t repack_sticky;  // this frame has few samples per stream: a shard that has re-packed once re-packs in every launch (want_compact)
     float sparse_below;      // fused one-ray-per-lane kernel: a launch that starts with alive < sparse_below * length advances one
                              // vertex only (and re-packs), instead of running `bounces` vertices on mostly idle wavefronts
     uint32_t finish_below;   // fused kernel: once a shard has no more alive paths than this, a launch runs them to their end

@@ -145,7 +145,7 @@ class Renderer:
 
     def SetTuning(self, **kw):
         """Scheduling knobs of the context (include/ptrt.h pt_tuning: bounces, loops, finish_below, packed_chunk, compact_below,
-        sparse_below). None changes a pixel."""
+        sparse_below, sticky_samples). None changes a pixel."""
         t = self.GetTuning()
         for k, v in kw.items():
             if not hasattr(t, k) or k == "reserved":

@@ -474,20 +474,22 @@ def test_shard_groups_on_separate_streams(P, pto, monkeypatch):
 
 @pytest.mark.parametrize("flags", [0, 4, 128, 64, 68])  # fused one-ray-per-lane / lane-packing / pooled kernels, and the first two followed by k_shade (PT_FLAG_SPLIT_KERNELS)
 def test_queue_compaction_policy_is_invisible(P, pto, monkeypatch, flags):
-    """pt_tuning.compact_below: queues carried over in place with holes (0 = never re-packed), re-packed every iteration (2), or
-    re-packed when alive/length < 0.9 — scheduling only: frame and ray count stay the oracle's. The streams end at
-    different iterations (spp 7 over 4 streams, Russian roulette), so the in-place runs do see holes."""
+    """pt_tuning.compact_below / sticky_samples: queues carried over in place with holes (0 = never re-packed), re-packed every
+    launch (2), re-packed when the predicted alive/length ratio is < 0.9 or 0.5, and the short-frame rule (2 samples per stream:
+    every launch) — scheduling only: frame and ray count stay the oracle's. The streams end at different iterations (spp 7 over
+    4 streams, Russian roulette), so the in-place runs do see holes."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 4, 200, 150)
     p = P.make_params(200, 150, spp=7, max_depth=12, streams=4, flags=flags)
     frames = []
-    for thr in ("0", "2", "0.9", "0.5"):
+    for thr, sticky in ((0.0, 0), (2.0, 0), (0.9, 0), (0.5, 0), (0.9, 32), (0.0, 32)):
         r = P.Renderer(P.Window(200, 150)); r.Init()
-        r.SetTuning(compact_below=float(thr))
+        r.SetTuning(compact_below=thr, sticky_samples=sticky)
+        assert r.GetTuning().sticky_samples == sticky
         try:
             r.SetScene(sd, 0); r.Params = p
             st = r.Render(0.0)
             frames.append((st.rays, r.ReadFramebuffer(), st.reserved[1], st.iterations))
-            if thr == "0":
+            if thr == 0.0 and sticky == 0:
                 info = r.BvhInfo()
                 ref, ost = pto.render(pto.Scene(sd, (info.width,) + r.BvhRead()), p)
                 assert ost.rays == st.rays and np.array_equal(frames[-1][1], ref)
@@ -495,6 +497,31 @@ def test_queue_compaction_policy_is_invisible(P, pto, monkeypatch, flags):
             r.Dispose()
     assert all(f[0] == frames[0][0] and np.array_equal(f[1], frames[0][1]) for f in frames)
     assert frames[0][2] == 0 and frames[1][2] > frames[2][2] > 0  # (shard, iteration) pairs that re-packed
+    assert frames[4][2] == frames[1][2] and frames[5][2] == 0      # short frame: every launch; compact_below 0 switches that off too
+
+
+@pytest.mark.parametrize("flags", [8, 128])
+def test_sticky_repacking_of_short_frames(P, pto, flags):
+    """A frame of few samples per stream (here 3) re-packs a shard's queue in every launch once the shard has re-packed at all;
+    with sticky_samples = 0 only the predicted ratio decides. Same picture, more re-packs."""
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL, 0, 9, 256, 160)
+    p = P.make_params(256, 160, spp=12, max_depth=8, streams=4, flags=flags)
+    out = []
+    for sticky in (0, 32):
+        r = P.Renderer(P.Window(256, 160)); r.Init()
+        r.SetTuning(sticky_samples=sticky, finish_below=0, bounces=2)
+        try:
+            r.SetScene(sd, 0); r.Params = p
+            st = r.Render(0.0)
+            out.append((st.rays, r.ReadFramebuffer(), st.reserved[1]))
+            if sticky == 0:
+                info = r.BvhInfo()
+                ref, ost = pto.render(pto.Scene(sd, (info.width,) + r.BvhRead()), p)
+                assert ost.rays == st.rays and np.array_equal(out[-1][1], ref)
+        finally:
+            r.Dispose()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    assert out[1][2] > out[0][2] > 0
 
 
 @pytest.mark.parametrize("kflag", [8, 128])  # one ray per lane, pooled
