@@ -20,6 +20,8 @@ Extra objects on the JSON line (rank 0, N = 1 only; all measured outside the tim
                    gather       node + triangle records fetched per second against tools/ubench/gather_tree run live at the
                                 scene's footprint: the same dependent 64-byte gathers with no arithmetic at all
                    hbm_measured rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch / live launch duration / 8 TB/s
+                 Launch durations are taken on a frame with PT_FLAG_PROFILE_KERNELS: full-grid launches, one after the other (the
+                 timed frames run two half-grid shard-group loops on two streams whose launches overlap — roofline.timed_region).
                  hbm_algorithmic (SURVEY §8d's bytes-per-ray formula) is reported next to them but is NOT a roofline here: those
                  bytes are served by L1/L2/Infinity Cache, so the figure can exceed the HBM peak (it did in round 1).
   parity       : rmse_vs_oracle and pixels_differing of the benchmarked frame against the scalar C oracle at the same spp and seed.
@@ -58,6 +60,8 @@ def main():
                          "in registers over several vertices and refills a finished path from its own stream, so it wants samples "
                          "per stream more than it wants slots; and with one K the N-rank frame is the single-rank frame bit for bit")
     ap.add_argument("--bvh-width", type=int, default=0, help="0 = library default (68 = BVH4Q)")
+    ap.add_argument("--loops", type=int, default=0, help="pt_tuning.loops for the timed frames: 0 = library default (two shard-group loops "
+                                                         "on two streams, launch tails overlap); 1 = every launch has the GPU to itself")
     ap.add_argument("--kernel", default="auto", choices=["auto", "simple", "packed", "pool"],
                     help="extend kernel: auto = probed per scene in the first frame (the default), else forced (profiling passes force it so that "
                          "no probe iteration sits inside the one profiled frame)")
@@ -106,6 +110,8 @@ def main():
     sd = P.make_scene(kinds[args.scene], args.tris, 0x5EED0001, W, H)
     r = P.Renderer(P.Window(W, H), device_ordinal=device)
     r.Init()
+    if args.loops:
+        r.SetTuning(loops=args.loops)
     t0 = time.time()
     r.SetScene(sd, args.bvh_width)
     commit_s = time.time() - t0
@@ -193,6 +199,10 @@ def main():
     # ---- roofline of the dominant kernel (untimed extra frames)
     if single and not args.no_roofline:
         out["roofline"] = roofline(P, r, mk, args, info, kernel_choice, W, H)
+        out["roofline"]["timed_region"] = {"loops": int(r.GetTuning().loops) or 2, "frame_ms": out["ms_per_step"],
+                                           "note": "the timed frames run the library default: two independent shard-group loops on two streams, "
+                                                   "half-grid launches that overlap; launch durations and ceilings above are from frames whose "
+                                                   "launches are full-grid and serialised (PT_FLAG_PROFILE_KERNELS), frame_ms_profiled each"}
     # ---- oracle legs: parity of the benchmarked frame + CPU baseline
     if single and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -150,8 +150,8 @@ typedef struct {
 typedef struct {
     uint32_t bounces;       /* path vertices a lane advances per launch of the fused extend kernels, 1..64; 0 (default) = max_depth / 2
                                clamped to [4, 8] */
-    uint32_t loops;         /* independent shard-group wavefront loops per frame, each on its own stream: 1, 2 or 4; 0 (default) = two for
-                               frames of at most 12 M slots (a rank's share), else one */
+    uint32_t loops;         /* independent shard-group wavefront loops per frame, each on its own stream: 1, 2 or 4; 0 (default) = two
+                               (frames with PT_FLAG_PROFILE_KERNELS / PT_FLAG_COUNT_VISITS always run one: their kernels are timed alone) */
     uint32_t finish_below;  /* a shard with at most this many live paths runs them to their end in one launch (default 4096; 0 = never) */
     uint32_t packed_chunk;  /* queue entries per wavefront of the lane-packing kernel, >= 64; 0 (default) = 256 with >= 4 streams, else 128 */
     float compact_below;    /* a shard re-packs its queue in a launch that would otherwise leave alive < this * length behind (default 0.9;

@@ -25,7 +25,6 @@ thread_local std::string g_err;
 constexpr uint32_t kLag = 4; // wavefront iterations kept in flight before the host looks at a queue size
 constexpr uint32_t kRingWords = kShards * kCounterStride; // one iteration's readback: (up to) the kShards extend-queue sizes
 constexpr uint32_t kMaxGroups = 4;  // independent wavefront loops (shard groups) per frame, each on its own stream
-constexpr uint32_t kTwoLoopsBelow = 12u << 20; // slots; see pt_context::groups
 constexpr size_t kFinalOffset = (size_t)kMaxGroups * kLag * kRingWords; // where the frame-end copy of all counters lands in h_counts
 
 uint32_t host_pcg(uint32_t x)
@@ -71,11 +70,12 @@ struct pt_context {
     hipEvent_t ev_lag[kMaxGroups][kLag] = {};
     hipStream_t group_stream[kMaxGroups] = {}; // group 0 runs on `stream` when there is one group only
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups] = {};
-    uint32_t groups = 0;                        // pt_tuning.loops (1, 2, 4) overrides; 0 = by frame size: frames of <= kTwoLoopsBelow slots run
-                                                // two loops, whose launch tails overlap (1M-tri Cornell: a rank's 1/8 of the 1080p frame
-                                                // 4.11 -> 3.81 ms, 1/4 7.14 -> 6.62 ms; four loops are slower, the host cannot feed them).
-                                                // Big frames (the 1-GPU headline: 16.6 M slots) keep one loop: the gain is 3 % there, and a
-                                                // launch timed by HIP events, by rocprofv3 and in the benchmark frame stays one and the same thing
+    uint32_t groups = 0;                        // pt_tuning.loops (1, 2, 4) overrides; 0 = two loops, whose launch tails overlap. Measured
+                                                // (tools/exp_loops.py, ms per frame with 1 / 2 / 4 loops): 1M-tri Cornell 1080p/64spp 18.42 /
+                                                // 18.08 / 18.77, a rank's 1/8 of it 4.11 / 3.81 / -, soup 76.2 / 73.3 / 72.3, glass 256 spp
+                                                // 37.8 / 37.0 / 36.6, 4K/1024 spp 1062 / 1051 / 1046. Frames that time single kernels
+                                                // (PT_FLAG_PROFILE_KERNELS, visit counting, the extend-kernel probe) run one loop, so that
+                                                // a timed launch has the GPU to itself.
     uint32_t bounces = 0;                       // pt_tuning.bounces (1..64): path vertices per launch of the fused kernel (state in registers);
                                                 // 0 = max_depth / 2 clamped to [4, 8] (measured: depth 8 -> 4 is best, 12.9 vs 12.3 Grays/s at 8;
                                                 // depth 16 with glass -> 8 is best, 23.0 vs 20.6 at 4)
@@ -634,7 +634,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     const bool undecided = forced_choice == 0u && s->ext_choice == 0u && !count && !profile;
     const uint32_t frame_kernel = (undecided && s->rate_simple > 0.0 && s->rate_packed == 0.0) ? (uint32_t)EXT_PACKED : (uint32_t)EXT_SIMPLE;
     const bool will_probe = undecided && frame_kernel == (uint32_t)EXT_SIMPLE;
-    const uint32_t n_loops = (profile || count || will_probe) ? 1u : c->groups ? c->groups : (n_slots <= kTwoLoopsBelow ? 2u : 1u);
+    const uint32_t n_loops = (profile || count || will_probe) ? 1u : c->groups ? c->groups : 2u;
     const uint32_t per_group = kShards / n_loops;
     //
     // Queues are carried over IN PLACE from one iteration to the next: a lane writes its own queue position, dead paths

@@ -2,7 +2,8 @@
 
     python tools/make_profiles.py gpurun_out/prof_r02 profiles/r02
 
-Writes <out>/kernel_stats_bench_default.csv (rocprofv3 --kernel-trace --stats of the default `python bench.py`),
+Writes <out>/kernel_stats_bench_default.csv (rocprofv3 --kernel-trace --stats of the default `python bench.py`), kernel_stats_bench_loops1.csv
+(the same with --loops 1: serialised full-grid launches),
 <out>/bench_line_under_trace.json, <out>/pmc_per_kernel.csv (every counter of every pass, per kernel), <out>/counters_dominant_kernel.txt
 and profiles/pmc_latest.json — what bench.py reads for roofline.valu_issue / hbm_measured / traffic when its workload matches the key.
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and on gfx950 FETCH_SIZE tallies 128-B requests at 64 B
@@ -20,6 +21,12 @@ src, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(out, "kernel_stats_bench_default.csv"))
 shutil.copy(os.path.join(src, "bench_line_under_trace.json"), os.path.join(out, "bench_line_under_trace.json"))
+# the same command with --loops 1 (full-grid launches, one at a time: the launches roofline.mean_launch_ms is about; in the default run
+# two half-grid launches of the two shard-group loops are in flight together, so its per-launch durations overlap)
+trace1 = os.path.join(src, "trace1", "trace_kernel_stats.csv")
+if os.path.exists(trace1):
+    shutil.copy(trace1, os.path.join(out, "kernel_stats_bench_loops1.csv"))
+    shutil.copy(os.path.join(src, "bench_line_under_trace_loops1.json"), os.path.join(out, "bench_line_under_trace_loops1.json"))
 
 
 def short(name):
@@ -54,15 +61,15 @@ hbm = (2 * pl.get("FETCH_SIZE", 0.0) + pl.get("WRITE_SIZE", 0.0)) * 1024
 
 # kernel-trace: average duration of the dominant kernel in the un-countered run
 avg_ns = None
-with open(os.path.join(src, "trace", "trace_kernel_stats.csv")) as fh:
+with open(trace1 if os.path.exists(trace1) else os.path.join(src, "trace", "trace_kernel_stats.csv")) as fh:
     for row in csv.DictReader(fh):
         if short(row["Name"]) == dom:
             avg_ns = float(row["AverageNs"])
 clock = pl["GRBM_GUI_ACTIVE"] / 8.0 / avg_ns if avg_ns and "GRBM_GUI_ACTIVE" in pl else None  # GHz; GUI_ACTIVE is summed over the 8 XCDs
 
 with open(os.path.join(out, "counters_dominant_kernel.txt"), "w") as f:
-    f.write(f"rocprofv3 --pmc passes (tools/profile_pmc.sh: one counter group per run) over `python3 bench.py --kernel simple --steps 1 --warmup 0 "
-            f"--no-cpu-baseline --no-roofline`\n(MI355X; sums over the frame's {n} launches of {dom}; {rays_per_frame} rays per frame)\n\n")
+    f.write(f"rocprofv3 --pmc passes (tools/profile_pmc.sh: one counter group per run) over `python3 bench.py --kernel simple --loops 1 --steps 1 --warmup 0 "
+            f"--no-cpu-baseline --no-roofline --no-configs`\n(MI355X; sums over the frame's {n} launches of {dom}; {rays_per_frame} rays per frame)\n\n")
     for c in sorted(per[dom]):
         f.write(f"{c:40s} {per[dom][c]:14.6g}   per launch {pl[c]:14.6g}\n")
     iv, tc, wc = per[dom]["SQ_INSTS_VALU"], per[dom]["SQ_THREAD_CYCLES_VALU"], per[dom]["SQ_WAVE_CYCLES"]
@@ -83,7 +90,7 @@ latest = {
     "workload_key": key, "kernel": dom, "launches_profiled": n, "rays_per_launch": rays_per_frame / n,
     "per_launch": {c: pl[c] for c in sorted(pl)}, "hbm_bytes_per_launch": round(hbm), "effective_clock_ghz": round(clock, 2) if clock else None,
     "source": f"{out}/pmc_per_kernel.csv: rocprofv3 --pmc, one counter group per run, over `bench.py --kernel simple --steps 1 --warmup 0 --no-cpu-baseline "
-              f"--no-roofline --no-configs`; means over the {n} launches of {dom} in the frame; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+              f"--no-roofline --no-configs --loops 1`; means over the {n} launches of {dom} in the frame; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
               "(FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section)",
     "workload": line["config"]["workload"],
 }
