@@ -572,8 +572,8 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     const uint64_t allocs_before = g_device_allocs;
     HIP_TRY(c, c->ray_o.ensure(n_slots)); HIP_TRY(c, c->ray_d.ensure(n_slots)); HIP_TRY(c, c->thr.ensure(n_slots));
     HIP_TRY(c, c->acc.ensure(n_slots)); HIP_TRY(c, c->tiles.ensure(pixel_slots)); HIP_TRY(c, c->hit.ensure(n_slots)); HIP_TRY(c, c->sd.ensure(n_slots));
-    // every queue = kShards regions of shard_cap entries; shard s owns the 256-slot groups g with g % kShards == s
-    const uint32_t groups = n_slots / kBlock, shard_cap = ((groups + kShards - 1) / kShards) * kBlock;
+    // every queue = kShards regions of shard_cap entries; shard s owns the 2^kShardGroupShift-slot groups g with g % kShards == s
+    const uint32_t groups = (n_slots + (1u << kShardGroupShift) - 1u) >> kShardGroupShift, shard_cap = ((groups + kShards - 1) / kShards) << kShardGroupShift;
     const size_t q_entries = (size_t)kShards * shard_cap;
     HIP_TRY(c, c->q_ext0.ensure(q_entries)); HIP_TRY(c, c->q_ext1.ensure(q_entries));
     for (auto &q : c->q_b) HIP_TRY(c, q.ensure(q_entries));

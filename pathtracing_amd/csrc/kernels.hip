@@ -90,7 +90,7 @@ PT_DEV size_t slot_of(uint32_t pixel_slot, uint32_t stream, uint32_t streams, ui
 }
 
 // Which shard and which block of that shard's queue a workgroup is. PT_SHARD_FASTEST: a 1-D grid with the shard as the
-// fastest index, so that workgroups are dispatched in slot order (shard s holds every 64th 256-slot group) and, with the
+// fastest index, so that workgroups are dispatched in slot order (shard s holds every 64th group of 2^kShardGroupShift slots) and, with the
 // dispatcher dealing workgroups round-robin to the 8 XCDs, a shard's workgroups always land on the same XCD.
 #ifndef PT_SHARD_FASTEST
 #define PT_SHARD_FASTEST 1
@@ -141,13 +141,13 @@ __global__ void __launch_bounds__(kBlock) k_reference_sphere(uint32_t w, uint32_
 }
 
 // ------------------------------------------------------------------------------------------------
-// grid (shard_cap/256, kShards): entry j of shard s is slot ((j>>8)*kShards + s)*256 + (j&255)
+// grid (ceil(shard_cap/256), kShards): entry j of shard s is slot ((j>>G)*kShards + s)*2^G + (j & (2^G - 1)), G = kShardGroupShift
 __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState ps, FrameParams fp)
 {
     uint32_t shard, bx, nbx;
     block_pos(ps, shard, bx, nbx);
     const uint32_t j = bx * kBlock + threadIdx.x;
-    const uint32_t slot = (((j >> 8) * kShards + shard) << 8) | (j & 255u);
+    const uint32_t slot = (((j >> kShardGroupShift) * kShards + shard) << kShardGroupShift) | (j & ((1u << kShardGroupShift) - 1u));
     uint32_t x = 0, y = 0;
     const bool in_range = j < ps.shard_cap && slot < ps.n_slots;
     // stream k takes the samples s with (sample_offset + s) % K == k, in increasing s (docs/SPEC.md §5)

@@ -10,6 +10,14 @@ constexpr uint32_t kTileShift = 6;                 // 64x64 tiles (docs/SPEC.md 
 constexpr uint32_t kTile = 1u << kTileShift;
 constexpr uint32_t kTilePixels = kTile * kTile;
 constexpr uint32_t kBlock = 256;                   // threads per workgroup = 4 wavefronts
+#ifndef PT_SHARD_GROUP_SHIFT
+#define PT_SHARD_GROUP_SHIFT 6
+#endif
+// Consecutive slots that share a shard: 2^this. 64 = one wavefront: consecutive wavefronts (the sample streams of one 8x8 pixel
+// block) go to consecutive shards, i.e. to different XCDs, and every shard gets an even cut of every tile. Measured, ms per frame
+// with groups of 64 / 256 / 512 / 1024 / 4096 slots: headline 17.91 / 18.01 / 18.29 / 18.18 / 18.70; a rank's 1/8 of it 2.65 / 2.72 /
+// 2.71 / 2.62 / 3.16; 512 spp 135.9 / 137.1 / 138.5 / 139.0 / 142.2; glass 256 spp 38.9 / 39.1 / 39.5 / 39.8 / 40.7; soup ±0.5 %.
+constexpr uint32_t kShardGroupShift = PT_SHARD_GROUP_SHIFT;
 #ifndef PT_STACK_LDS
 #define PT_STACK_LDS 12
 #endif
@@ -25,7 +33,7 @@ constexpr uint32_t kMaxSpheres = 64;
 constexpr uint32_t kPool = PT_POOL;                // queue entries per wavefront of k_extend_pool (64 P)
 enum ExtendKernel : int { EXT_SIMPLE = 1, EXT_PACKED = 2, EXT_POOL = 3 }; // pt_stats.reserved[0]
 
-// Queue sharding. A slot belongs to shard (slot >> 8) % kShards for the whole frame, every queue is kShards
+// Queue sharding. A slot belongs to shard (slot >> kShardGroupShift) % kShards for the whole frame, every queue is kShards
 // independent regions of `shard_cap` entries with one counter line each, and a workgroup works on exactly one shard
 // (kernels.hip block_pos: 1-D grids with the shard as the fastest index).
 // Why: a queue push is one returning atomic per wavefront; on ONE address that saturates at ~88 atomics/us
@@ -91,7 +99,7 @@ struct PathState {           // SoA over slots
     int32_t *stack_ovf;      // traversal stack overflow, [entry][kShards * shard_cap]
     uint32_t stack_ovf_entries;
     uint32_t n_slots;
-    uint32_t shard_cap;      // entries per shard region = slots owned by a shard (multiple of 256)
+    uint32_t shard_cap;      // entries per shard region = slots owned by a shard (multiple of 2^kShardGroupShift)
     uint32_t shard_base, shard_count; // the shards this launch covers: shard_base .. + shard_count (groups of shards run as
                                       // independent wavefront loops on their own streams, see api.cpp)
     // queue policy, decided on the device from the shard's own counters (no host lag):

@@ -496,7 +496,7 @@ def test_queue_compaction_policy_is_invisible(P, pto, monkeypatch, flags):
         finally:
             r.Dispose()
     assert all(f[0] == frames[0][0] and np.array_equal(f[1], frames[0][1]) for f in frames)
-    assert frames[0][2] == 0 and frames[1][2] > frames[2][2] > 0  # (shard, iteration) pairs that re-packed
+    assert frames[0][2] == 0 and frames[1][2] >= frames[2][2] > 0  # (shard, iteration) pairs that re-packed (the lane-packing kernel ends this small frame in one)
     assert frames[4][2] == frames[1][2] and frames[5][2] == 0      # short frame: every launch; compact_below 0 switches that off too
 
 
