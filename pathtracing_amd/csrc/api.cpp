@@ -617,11 +617,11 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     HIP_TRY(c, launch_generate(q, sc, ps, fp));
 
     // Wavefront loops. Shards never exchange slots, so the 64 shards are split into `n_loops` independent loops, each on
-    // its own HIP stream: while one group traverses (bound by cache gathers) another shades (bound by HBM streaming),
-    // and the tails of one group's launches are filled by the other's. Measured +13 % (Cornell 1M) ... +22 % (soup) over
-    // one loop. Inside a loop a shard's queue can only shrink (slots die, none are born), so the queue sizes read back
-    // kLag iterations ago are valid launch bounds: the host never stalls the GPU to size a grid.
-    // per-kernel timing, visit counting and the extend-kernel probe (events around single iterations) want kernels alone on the GPU
+    // its own HIP stream: the tail of one group's launch (its last wavefronts draining) is filled by the other's launch
+    // (pt_context::groups has the measurements). Inside a loop a shard's queue can only shrink (slots die, none are born),
+    // so the queue sizes read back kLag iterations ago are valid launch bounds: the host never stalls the GPU to size a grid.
+    // Per-kernel timing, visit counting and the extend-kernel probe (events around single iterations) want kernels alone on
+    // the GPU: one loop.
     // Which extend kernel (when no flag forces one): measured, per scene, and remembered in the scene.
     //   inside a frame : iteration 2 of group 0 runs the one-ray-per-lane kernel, iteration 3 the lane-packing one (bit-identical
     //                    results), each bracketed by events; accepted only if both traced a real share of the frame's slots;
