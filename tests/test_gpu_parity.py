@@ -583,27 +583,38 @@ def test_app_runs_the_reference_frame(P, pto):
 
 
 def test_randomised_configurations_against_the_oracle(P, pto, renderer):
-    """A fixed-seed sweep over scene kind, frame size (ragged tiles), spp, depth, streams, node layout, extend kernel, pipeline
-    and sample offset: every combination must reproduce the oracle's frame, ray count and visit counters bit for bit. Guards
-    the interplay of the scheduling features (in-place queues, re-packing, run-to-end tail, bounces per launch, shard loops)."""
+    """A fixed-seed sweep over scene kind, frame size (ragged tiles), spp, depth, streams, node layout, extend kernel, pipeline,
+    sample offset and the scheduling knobs (pt_tuning: loops, bounces per launch, re-packing threshold and sticky limit, run-to-end
+    threshold): every combination must reproduce the oracle's frame, ray count and visit counters bit for bit. Guards the
+    interplay of the scheduling features (in-place queues, predicted / sticky / forced re-packing, run-to-end tail, shard loops)."""
     N = P.native
     rng = np.random.default_rng(20261005)
     kinds = [(N.PT_SCENE_CORNELL, 0), (N.PT_SCENE_CORNELL_GLASS, 0), (N.PT_SCENE_TRIANGLE_SOUP, 3000), (N.PT_SCENE_CORNELL_TESS, 2500)]
-    for case in range(60):
-        kind, detail = kinds[int(rng.integers(len(kinds)))]
-        w, h = int(rng.integers(1, 150)), int(rng.integers(1, 110))
-        spp, depth = int(rng.integers(1, 12)), int(rng.integers(1, 14))
-        streams = int(rng.choice([0, 1, 2, 3, 8, 16]))
-        width = int(rng.choice([0, 2, 4, 68, 72]))
-        flags = int(rng.choice([0, 0, N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_EXTEND_SIMPLE, N.PT_FLAG_EXTEND_POOL, N.PT_FLAG_EXTEND_POOL,
-                                N.PT_FLAG_SPLIT_KERNELS, N.PT_FLAG_SPLIT_KERNELS | N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_BUCKET_SPECULAR]))
-        offset = int(rng.integers(0, 5))
-        sd = P.make_scene(kind, detail, int(rng.integers(1, 1 << 30)), w, h)
-        p = P.make_params(w, h, spp=spp, max_depth=depth, streams=streams, flags=flags, sample_offset=offset, seed=int(rng.integers(1 << 31)))
-        count = case % 2 == 0  # the counting and the plain instantiations of the kernels are different code objects: cover both
-        img, st, ref, ost = run_both(P, pto, renderer, sd, p, width, count=count)
-        ctx = (case, kind, w, h, spp, depth, streams, width, flags, offset)
-        assert st.rays == ost.rays and st.paths == ost.paths, ctx
-        assert np.array_equal(img, ref), ctx
-        if count:
-            assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests), ctx
+    defaults = renderer.GetTuning()
+    try:
+        for case in range(72):
+            kind, detail = kinds[int(rng.integers(len(kinds)))]
+            w, h = int(rng.integers(1, 150)), int(rng.integers(1, 110))
+            spp, depth = int(rng.integers(1, 12)), int(rng.integers(1, 14))
+            if case % 9 == 8:
+                spp = int(rng.integers(34, 48))  # many samples per stream: the predicted-ratio rule, not the sticky one
+            streams = int(rng.choice([0, 1, 2, 3, 8, 16]))
+            width = int(rng.choice([0, 2, 4, 68, 72]))
+            flags = int(rng.choice([0, 0, N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_EXTEND_SIMPLE, N.PT_FLAG_EXTEND_POOL, N.PT_FLAG_EXTEND_POOL,
+                                    N.PT_FLAG_SPLIT_KERNELS, N.PT_FLAG_SPLIT_KERNELS | N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_BUCKET_SPECULAR]))
+            offset = int(rng.integers(0, 5))
+            tune = dict(loops=int(rng.choice([0, 1, 2, 4])), bounces=int(rng.choice([0, 0, 1, 2, 3, 5, 8])),
+                        compact_below=float(rng.choice([0.0, 0.5, 0.9, 0.9, 1.0, 2.0])), sticky_samples=int(rng.choice([0, 2, 32, 32, 1000])),
+                        finish_below=int(rng.choice([0, 64, 4096, 4096, 1 << 20])))
+            renderer.SetTuning(**tune)
+            sd = P.make_scene(kind, detail, int(rng.integers(1, 1 << 30)), w, h)
+            p = P.make_params(w, h, spp=spp, max_depth=depth, streams=streams, flags=flags, sample_offset=offset, seed=int(rng.integers(1 << 31)))
+            count = case % 2 == 0  # the counting and the plain instantiations of the kernels are different code objects: cover both
+            img, st, ref, ost = run_both(P, pto, renderer, sd, p, width, count=count)
+            ctx = (case, kind, w, h, spp, depth, streams, width, flags, offset, tune)
+            assert st.rays == ost.rays and st.paths == ost.paths, ctx
+            assert np.array_equal(img, ref), ctx
+            if count:
+                assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests), ctx
+    finally:
+        renderer.SetTuning(**{k: getattr(defaults, k) for k in ("bounces", "loops", "finish_below", "packed_chunk", "compact_below", "sparse_below", "sticky_samples")})
