@@ -47,8 +47,8 @@ KERNEL_NAMES = {0: "unprobed", 1: "k_extend", 2: "k_extend_packed", 3: "k_extend
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default="cornell_tess", choices=["cornell_tess", "cornell", "cornell_glass", "soup"])
     ap.add_argument("--tris", type=int, default=1 << 20)
     ap.add_argument("--width", type=int, default=1920)
