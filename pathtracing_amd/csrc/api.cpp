@@ -614,7 +614,9 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     hipStream_t q = c->stream;
     HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * kCntTotalWords, q));
     HIP_TRY(c, hipEventRecord(c->ev_start, q));
-    HIP_TRY(c, launch_generate(q, sc, ps, fp));
+    // the fused one-ray-per-lane and lane-packing kernels build a slot's initial state in registers in their first launch; k_shade
+    // (split pipelines) and the pooled kernel read it from memory
+    HIP_TRY(c, launch_generate(q, sc, ps, fp, split_kernels || forced_choice == (uint32_t)EXT_POOL));
 
     // Wavefront loops. Shards never exchange slots, so the 64 shards are split into `n_loops` independent loops, each on
     // its own HIP stream: the tail of one group's launch (its last wavefronts draining) is filled by the other's launch

@@ -141,39 +141,6 @@ __global__ void __launch_bounds__(kBlock) k_reference_sphere(uint32_t w, uint32_
 }
 
 // ------------------------------------------------------------------------------------------------
-// grid (ceil(shard_cap/256), kShards): entry j of shard s is slot ((j>>G)*kShards + s)*2^G + (j & (2^G - 1)), G = kShardGroupShift
-__global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState ps, FrameParams fp)
-{
-    uint32_t shard, bx, nbx;
-    block_pos(ps, shard, bx, nbx);
-    const uint32_t j = bx * kBlock + threadIdx.x;
-    const uint32_t slot = (((j >> kShardGroupShift) * kShards + shard) << kShardGroupShift) | (j & ((1u << kShardGroupShift) - 1u));
-    uint32_t x = 0, y = 0;
-    const bool in_range = j < ps.shard_cap && slot < ps.n_slots;
-    // stream k takes the samples s with (sample_offset + s) % K == k, in increasing s (docs/SPEC.md §5)
-    const uint32_t stream = slot_stream(slot, fp);
-    const uint32_t first = (stream + fp.streams - fp.sample_offset % fp.streams) % fp.streams;
-    const bool valid = in_range && first < fp.spp && slot_pixel(slot, fp, x, y);
-    if (in_range && !fp.accumulate) ps.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) {
-        const uint32_t key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset + first);
-        V3 o, d;
-        camera_ray_of(sc.cam, x, y, key, o, d);
-        ps.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
-        ps.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
-        ps.thr[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(key));
-        ps.sd[slot] = first << 8;
-    }
-    // the first queue is the shard's slots in slot order, holes (off-image pixels, streams with no sample) included
-    if (j < ps.shard_cap) ps.q_ext[0][(size_t)shard * ps.shard_cap + j] = valid ? slot : kInvalidSlot;
-    const uint32_t n_alive = (uint32_t)__syncthreads_count(valid);
-    if (threadIdx.x == 0) {
-        if (n_alive) atomicAdd(&ps.counters[cnt_alive_index(0, shard)], n_alive);
-        if (bx == 0) ps.counters[cnt_ext_index(0, shard)] = ps.shard_cap;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // One inner-node visit for node layout L (PT_BVH_WIDTH_*): fetch the node, slab-test its children against the ray,
 // return (key, ref) sorted by ascending key = (bits(tn) & ~3) | slot; children that are missed/empty get key ~0.
 // L = 2 / 4 : N slots of {lo.xyz|ref, hi.xyz|0}  -> 2N 16-byte loads per lane
@@ -341,6 +308,54 @@ PT_DEV void path_store(const PathState &ps, uint32_t slot, const PathRegs &r)
     at(ps.thr, slot) = make_float4(r.T.x, r.T.y, r.T.z, __uint_as_float(r.key));
     at(ps.sd, slot) = (r.sample << 8) | r.depth;
 }
+
+// The first sample of a slot's stream: stream k takes the samples s with (sample_offset + s) % K == k, in increasing s (docs/SPEC.md §5).
+PT_DEV uint32_t first_sample(uint32_t slot, const FrameParams &fp)
+{
+    return (slot_stream(slot, fp) + fp.streams - fp.sample_offset % fp.streams) % fp.streams;
+}
+// The state a slot starts the frame with: the camera ray of its stream's first sample (slot_pixel(slot) must be on the image).
+PT_DEV void path_init(const DeviceScene &sc, const FrameParams &fp, uint32_t slot, PathRegs &r)
+{
+    uint32_t x = 0, y = 0;
+    slot_pixel(slot, fp, x, y);
+    r.sample = first_sample(slot, fp);
+    r.key = path_key(fp.seed_hashed, y * fp.width + x, fp.sample_offset + r.sample);
+    camera_ray_of(sc.cam, x, y, r.key, r.o, r.d);
+    r.T = v3(1.f, 1.f, 1.f);
+    r.depth = 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid (ceil(shard_cap/256), kShards): entry j of shard s is slot ((j>>G)*kShards + s)*2^G + (j & (2^G - 1)), G = kShardGroupShift
+__global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState ps, FrameParams fp, uint32_t full)
+{
+    uint32_t shard, bx, nbx;
+    block_pos(ps, shard, bx, nbx);
+    const uint32_t j = bx * kBlock + threadIdx.x;
+    const uint32_t slot = (((j >> kShardGroupShift) * kShards + shard) << kShardGroupShift) | (j & ((1u << kShardGroupShift) - 1u));
+    uint32_t x = 0, y = 0;
+    const bool in_range = j < ps.shard_cap && slot < ps.n_slots;
+    // stream k takes the samples s with (sample_offset + s) % K == k, in increasing s (docs/SPEC.md §5)
+    const uint32_t first = first_sample(slot, fp);
+    const bool valid = in_range && first < fp.spp && slot_pixel(slot, fp, x, y);
+    if (in_range && !fp.accumulate) ps.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // `full` == 0: the first launch of a fused extend kernel builds the state of its slots in registers (path_init) instead of
+    // reading it back: 52 bytes per slot not written here and not read there
+    if (valid && full) {
+        PathRegs r;
+        path_init(sc, fp, slot, r);
+        path_store(ps, slot, r);
+    }
+    // the first queue is the shard's slots in slot order, holes (off-image pixels, streams with no sample) included
+    if (j < ps.shard_cap) ps.q_ext[0][(size_t)shard * ps.shard_cap + j] = valid ? slot : kInvalidSlot;
+    const uint32_t n_alive = (uint32_t)__syncthreads_count(valid);
+    if (threadIdx.x == 0) {
+        if (n_alive) atomicAdd(&ps.counters[cnt_alive_index(0, shard)], n_alive);
+        if (bx == 0) ps.counters[cnt_ext_index(0, shard)] = ps.shard_cap;
+    }
+}
+
 
 template <int MODE>
 PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t slot, PathRegs &r, float t, uint32_t ref,
@@ -621,6 +636,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     if (active) {
         const PathState &ps = cold().ps;
         if (FUSE == SHADE_NONE) { r.o = xyz(at(ps.ray_o, slot)); r.d = xyz(at(ps.ray_d, slot)); }
+        else if (it == 0u) path_init(cold().sc, cold().fp, slot, r); // k_generate left the state to this launch (launch_generate)
         else path_load(ps, slot, r);
     }
     bool alive = active;
@@ -847,6 +863,7 @@ k_extend_packed(ExtArgs a)
                 if (FUSE != SHADE_NONE && !do_compact) q_next[pos] = kInvalidSlot;
             } else if (pull) {
                 if (FUSE == SHADE_NONE) { o = xyz(at(cold().ps.ray_o, slot)); d = xyz(at(cold().ps.ray_d, slot)); }
+                else if (it == 0u) path_init(cold().sc, cold().fp, slot, r); // see k_extend
                 else path_load(cold().ps, slot, r);
                 budget = budget0;
                 start_ray();
@@ -1215,9 +1232,9 @@ hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4
     return hipGetLastError();
 }
 
-hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp)
+hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, bool full_state)
 {
-    hipLaunchKernelGGL(k_generate, shard_grid(blocks_for(ps.shard_cap), ps.shard_count), dim3(kBlock), 0, s, sc, ps, fp);
+    hipLaunchKernelGGL(k_generate, shard_grid(blocks_for(ps.shard_cap), ps.shard_count), dim3(kBlock), 0, s, sc, ps, fp, full_state ? 1u : 0u);
     return hipGetLastError();
 }
 
