@@ -159,7 +159,8 @@ typedef struct {
     float sparse_below;     /* one-ray-per-lane kernel: a launch that starts with alive < this * length advances one vertex only (default 0 = off) */
     uint32_t sticky_samples; /* frames with at most this many samples per stream (spp / streams): a shard that has re-packed once re-packs
                                in every launch, and with at most 2 samples per stream every launch re-packs (default 32; 0 = off) */
-    uint32_t reserved;
+    uint32_t lag;           /* wavefront iterations the host runs ahead of the queue sizes it reads back: 2, 3 or 4; 0 (default) = 2 for
+                               frames of at most 2 samples per stream, else 3 */
 } pt_tuning; /* 32 B */
 
 /* ---- context: replaces GraphicsDevice.Init (GraphicsDevice.cs:38-43) + Renderer.CreateResources (Renderer.cs:105-196) */

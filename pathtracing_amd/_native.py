@@ -77,7 +77,7 @@ class pt_bvh_info(C.Structure):
 
 class pt_tuning(C.Structure):
     _fields_ = [("bounces", C.c_uint32), ("loops", C.c_uint32), ("finish_below", C.c_uint32), ("packed_chunk", C.c_uint32),
-                ("compact_below", C.c_float), ("sparse_below", C.c_float), ("sticky_samples", C.c_uint32), ("reserved", C.c_uint32)]
+                ("compact_below", C.c_float), ("sparse_below", C.c_float), ("sticky_samples", C.c_uint32), ("lag", C.c_uint32)]
 
 
 class pt_tile_layout(C.Structure):

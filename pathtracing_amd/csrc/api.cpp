@@ -22,7 +22,7 @@ namespace {
 
 thread_local std::string g_err;
 
-constexpr uint32_t kLag = 4; // wavefront iterations kept in flight before the host looks at a queue size
+constexpr uint32_t kLag = 4; // most wavefront iterations kept in flight before the host looks at a queue size (ring sizes; pt_tuning.lag)
 constexpr uint32_t kRingWords = kShards * kCounterStride; // one iteration's readback: (up to) the kShards extend-queue sizes
 constexpr uint32_t kMaxGroups = 4;  // independent wavefront loops (shard groups) per frame, each on its own stream
 constexpr size_t kFinalOffset = (size_t)kMaxGroups * kLag * kRingWords; // where the frame-end copy of all counters lands in h_counts
@@ -81,6 +81,7 @@ struct pt_context {
                                                 // depth 16 with glass -> 8 is best, 23.0 vs 20.6 at 4)
     double compact_below = 0.9;                // pt_tuning.compact_below: a shard re-packs its queue in a launch that would leave alive/length
                                                 // below this (>1 = every launch, 0 = never); else carried in place (want_compact, kernels.hip).
+    uint32_t lag = 0;                           // pt_tuning.lag (2..4; 0 = by frame length, see render_frame)
     uint32_t sticky_samples = 32;               // pt_tuning.sticky_samples. Measured, 1M-tri Cornell 1080p, ms per frame by spp (8 streams),
                                                 // start-of-launch ratio (round 1) / predicted ratio / sticky / every launch:
                                                 //   8: 4.13/4.20/4.07/3.01  32: 10.95/10.93/9.70/9.61  64: 19.28/18.82/18.45/18.36
@@ -229,7 +230,7 @@ pt_status pt_context_get_tuning(const pt_context *c, pt_tuning *o)
     if (!c || !o) return fail(nullptr, PT_ERR_INVALID_ARGUMENT, "pt_context_get_tuning: NULL argument");
     std::memset(o, 0, sizeof *o);
     o->bounces = c->bounces; o->loops = c->groups; o->finish_below = c->finish_below; o->packed_chunk = c->packed_chunk;
-    o->compact_below = (float)c->compact_below; o->sparse_below = (float)c->sparse_below; o->sticky_samples = c->sticky_samples;
+    o->compact_below = (float)c->compact_below; o->sparse_below = (float)c->sparse_below; o->sticky_samples = c->sticky_samples; o->lag = c->lag;
     return PT_OK;
 }
 
@@ -239,10 +240,11 @@ pt_status pt_context_set_tuning(pt_context *c, const pt_tuning *t)
     if (t->bounces > 64) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: bounces must be 0 (default) or 1..64");
     if (t->loops != 0 && t->loops != 1 && t->loops != 2 && t->loops != 4) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: loops must be 0 (default), 1, 2 or 4");
     if (t->packed_chunk != 0 && (t->packed_chunk < 64 || t->packed_chunk > (1u << 20))) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: packed_chunk must be 0 (default) or 64..2^20");
+    if (t->lag != 0 && (t->lag < 2 || t->lag > kLag)) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: lag must be 0 (default) or 2..%u", kLag);
     if (!(t->compact_below >= 0.f && t->compact_below <= 2.f) || !(t->sparse_below >= 0.f && t->sparse_below <= 1.f))
         return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: compact_below must be in [0,2], sparse_below in [0,1]");
     c->bounces = t->bounces; c->groups = t->loops; c->finish_below = t->finish_below; c->packed_chunk = t->packed_chunk;
-    c->compact_below = t->compact_below; c->sparse_below = t->sparse_below; c->sticky_samples = t->sticky_samples;
+    c->compact_below = t->compact_below; c->sparse_below = t->sparse_below; c->sticky_samples = t->sticky_samples; c->lag = t->lag;
     return PT_OK;
 }
 
@@ -621,7 +623,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     // Wavefront loops. Shards never exchange slots, so the 64 shards are split into `n_loops` independent loops, each on
     // its own HIP stream: the tail of one group's launch (its last wavefronts draining) is filled by the other's launch
     // (pt_context::groups has the measurements). Inside a loop a shard's queue can only shrink (slots die, none are born),
-    // so the queue sizes read back kLag iterations ago are valid launch bounds: the host never stalls the GPU to size a grid.
+    // so the queue sizes read back `lag` iterations ago are valid launch bounds: the host never stalls the GPU to size a grid.
     // Per-kernel timing, visit counting and the extend-kernel probe (events around single iterations) want kernels alone on
     // the GPU: one loop.
     // Which extend kernel (when no flag forces one): measured, per scene, and remembered in the scene.
@@ -652,6 +654,12 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
         if (loops[g].stream != q) HIP_TRY(c, hipStreamWaitEvent(loops[g].stream, c->ev_fork, 0));
     }
     const uint64_t max_iters = (uint64_t)p->spp * p->max_depth + kLag + 2;
+    // Iterations the host runs ahead of the queue sizes it reads back (pt_tuning.lag). The frame ends `lag` launches after its last
+    // path, on grids sized `lag` iterations ago: short frames feel that (ms per 1080p frame with lag 4 / 3 / 2, tools/exp_lag.py:
+    // 1 spp 0.567 / 0.537 / 0.529, 8 spp 2.79 / 2.73 / 2.70, glass 8 spp 1.57 / 1.52 / 1.48), long ones not (64 spp 17.73 / 17.68 /
+    // 17.73; a rank's 1/8 2.63 / 2.59 / 2.61), and the lane-packing kernel's short tail launches want the host further ahead (soup
+    // 72.3 / 72.4 / 73.1). At least 2: the launch after the last one that had paths clears that one's counter line.
+    const uint32_t lag = c->lag ? c->lag : samples_per_stream <= 2u ? 2u : 3u;
     size_t nev = 0;
     uint32_t iters_max = 0;
     // 0 = probing inside this frame, else the ExtendKernel every iteration uses
@@ -695,15 +703,15 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
             }
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u + 1u], L.stream)); // the whole iteration, either way
             if (profile) HIP_TRY(c, hipEventRecord(e2, L.stream));
-            const uint32_t ring = L.iters % kLag;
+            const uint32_t ring = L.iters % lag;
             uint32_t *h_ring = c->h_counts + ((size_t)g * kLag + ring) * kRingWords;
             HIP_TRY(c, hipMemcpyAsync(h_ring, c->counters.p + cnt_ext_index((it + 1u) % 3u, L.base), sizeof(uint32_t) * per_group * kCounterStride,
                                       hipMemcpyDeviceToHost, L.stream));
             HIP_TRY(c, hipEventRecord(c->ev_lag[g][ring], L.stream));
             ++L.iters;
             iters_max = std::max(iters_max, L.iters);
-            if (L.iters >= kLag) {
-                const uint32_t old = (L.iters - kLag) % kLag; // iteration iters-kLag: its survivors bound every later queue
+            if (L.iters >= lag) {
+                const uint32_t old = (L.iters - lag) % lag; // iteration iters-lag: its survivors bound every later queue
                 HIP_TRY(c, hipEventSynchronize(c->ev_lag[g][old]));
                 const uint32_t *h_old = c->h_counts + ((size_t)g * kLag + old) * kRingWords;
                 uint32_t mx = 0;
@@ -715,7 +723,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
                     traced += (uint64_t)h_old[sh * kCounterStride + 2] | ((uint64_t)h_old[sh * kCounterStride + 3] << 32);
                 }
                 L.bound = mx;
-                const uint32_t old_iter = L.iters - kLag; // iteration old_iter traced `traced` rays and left `total` paths alive
+                const uint32_t old_iter = L.iters - lag; // iteration old_iter traced `traced` rays and left `total` paths alive
                 if (trace) {
                     trace_alive.resize(std::max<size_t>(trace_alive.size(), old_iter + 1), 0); trace_rays.resize(trace_alive.size(), 0);
                     trace_alive[old_iter] += total; trace_rays[old_iter] += traced;

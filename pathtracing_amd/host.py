@@ -145,10 +145,10 @@ class Renderer:
 
     def SetTuning(self, **kw):
         """Scheduling knobs of the context (include/ptrt.h pt_tuning: bounces, loops, finish_below, packed_chunk, compact_below,
-        sparse_below, sticky_samples). None changes a pixel."""
+        sparse_below, sticky_samples, lag). None changes a pixel."""
         t = self.GetTuning()
         for k, v in kw.items():
-            if not hasattr(t, k) or k == "reserved":
+            if not hasattr(t, k):
                 raise AttributeError(f"pt_tuning has no field {k!r}")
             setattr(t, k, v)
         _check(N.lib.pt_context_set_tuning(self._ctx, C.byref(t)), self._ctx)
