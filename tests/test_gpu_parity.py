@@ -605,7 +605,7 @@ def test_randomised_configurations_against_the_oracle(P, pto, renderer):
             offset = int(rng.integers(0, 5))
             tune = dict(loops=int(rng.choice([0, 1, 2, 4])), bounces=int(rng.choice([0, 0, 1, 2, 3, 5, 8])),
                         compact_below=float(rng.choice([0.0, 0.5, 0.9, 0.9, 1.0, 2.0])), sticky_samples=int(rng.choice([0, 2, 32, 32, 1000])),
-                        finish_below=int(rng.choice([0, 64, 4096, 4096, 1 << 20])))
+                        finish_below=int(rng.choice([0, 64, 4096, 4096, 1 << 20])), lag=int(rng.choice([0, 0, 2, 3, 4])))
             renderer.SetTuning(**tune)
             sd = P.make_scene(kind, detail, int(rng.integers(1, 1 << 30)), w, h)
             p = P.make_params(w, h, spp=spp, max_depth=depth, streams=streams, flags=flags, sample_offset=offset, seed=int(rng.integers(1 << 31)))
@@ -617,4 +617,4 @@ def test_randomised_configurations_against_the_oracle(P, pto, renderer):
             if count:
                 assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests), ctx
     finally:
-        renderer.SetTuning(**{k: getattr(defaults, k) for k in ("bounces", "loops", "finish_below", "packed_chunk", "compact_below", "sparse_below", "sticky_samples")})
+        renderer.SetTuning(**{k: getattr(defaults, k) for k in ("bounces", "loops", "finish_below", "packed_chunk", "compact_below", "sparse_below", "sticky_samples", "lag")})
