@@ -12,8 +12,10 @@
 namespace ptrt {
 namespace {
 
+// Bins of the SAH sweep. Measured on the 1M-triangle Cornell (1080p / 64 spp): 16 / 32 / 64 bins = 7.72 / 7.63 / 7.60 node visits per
+// ray, 17.60 / 17.48 / 17.37 ms per frame, 0.46 / 0.52 / 0.58 s per commit (the soup: 29.05 / 28.95 / 28.91 visits, 1.12 / 1.25 / 1.48 s).
 #ifndef PT_SAH_BINS
-#define PT_SAH_BINS 16
+#define PT_SAH_BINS 64
 #endif
 constexpr int kBins = PT_SAH_BINS;
 constexpr uint32_t kMaxLeaf = 4;
