@@ -71,7 +71,7 @@ enum {
 };
 /* pt_scene_commit options */
 enum {
-    PT_BVH_WIDTH_DEFAULT = 0, /* PT_BVH_WIDTH_4Q; PT_BVH_WIDTH_8Q for scenes of at most 256 triangles (pt_bvh_info.width tells) */
+    PT_BVH_WIDTH_DEFAULT = 0, /* PT_BVH_WIDTH_4Q; PT_BVH_WIDTH_2 for scenes of at most 192 triangles (pt_bvh_info.width tells) */
     PT_BVH_WIDTH_2 = 2,       /* binary, 64-B nodes, f32 child boxes */
     PT_BVH_WIDTH_4 = 4,       /* 4-wide, 128-B nodes, f32 child boxes */
     PT_BVH_WIDTH_4Q = 68,     /* 4-wide, 64-B nodes, child boxes quantised to 8 bits on a per-node power-of-two grid */

@@ -361,10 +361,13 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     const bool lbvh = (bvh_width & PT_BVH_BUILD_LBVH) != 0; // hierarchy built on the GPU instead of the host SAH builder
     bvh_width &= ~(uint32_t)PT_BVH_BUILD_LBVH;
     if (lbvh && !c) return fail(c, PT_ERR_UNSUPPORTED, "PT_BVH_BUILD_LBVH needs a device context (detached scenes use the host builder)");
-    // default layout: BVH4Q; scenes of a few hundred triangles get BVH8Q — their whole tree is a handful of L1-resident lines and
-    // what counts is the number of dependent steps (Cornell: 1 node instead of 2 levels, 23.6 -> 24.8 Grays/s; Cornell+glass+metal
-    // 17.6 -> 20.0), while on big trees the 8-wide visit costs more ALU than the saved visits are worth (1M triangles: 11.1 vs 8.5)
-    if (bvh_width == PT_BVH_WIDTH_DEFAULT) bvh_width = s->tri_mat.size() <= 256 ? PT_BVH_WIDTH_8Q : PT_BVH_WIDTH_4Q;
+    // default layout: BVH4Q; scenes of up to ~200 triangles get BVH2 with float boxes — their whole tree is a handful of L1-resident
+    // lines, memory does not count and the 2-wide visit is the cheapest in ALU. ms per 1080p / 64 spp frame, BVH8Q | BVH4Q | BVH4 | BVH2
+    // (tools/exp_layouts.py): Cornell (12 triangles) 8.30 | 9.07 | 8.60 | 8.32, Cornell+glass+metal 9.82 | 11.34 | 9.82 | 9.18, walls of
+    // 42 triangles 17.7 | 12.2 | 11.4 | 11.4, of 162: 18.7 | 14.2 | 13.4 | 12.7, of 252: - | 13.0 | 13.7 | 13.4, of 1002: 20.2 | 14.2 | 16.5 |
+    // 15.0; soups of 100 / 400: - | 2.11 / 2.68 | 2.24 / 2.82 | 2.21 / 2.87. (Round 1 gave everything up to 256 triangles BVH8Q, on the
+    // strength of the 12-triangle box alone, where it is one node.)
+    if (bvh_width == PT_BVH_WIDTH_DEFAULT) bvh_width = s->tri_mat.size() <= 192 ? PT_BVH_WIDTH_2 : PT_BVH_WIDTH_4Q;
     if (bvh_width != PT_BVH_WIDTH_2 && bvh_width != PT_BVH_WIDTH_4 && bvh_width != PT_BVH_WIDTH_4Q && bvh_width != PT_BVH_WIDTH_8Q)
         return fail(c, PT_ERR_INVALID_ARGUMENT, "bvh_width must be one of PT_BVH_WIDTH_* (0, 2, 4, 68, 72)");
     if (!s->have_cam) return fail(c, PT_ERR_INVALID_ARGUMENT, "no camera set");

@@ -493,17 +493,16 @@ PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint
 //       others are still gathering nodes.
 // Counters are triple-buffered by iteration (cur = it % 3 is read, next is filled, the third is zeroed for the
 // iteration after), because a fused kernel fills `next` while other workgroups of the same launch are still starting.
-// Occupancy is worth more to this kernel than a few spills: it hides the latency of divergent node gathers with waves, and
-// unconstrained the fused variants take 84-89 VGPRs (5 waves/SIMD). Measured on the 1M-triangle Cornell box (Mrays/s):
-// 5 waves 9555, 6 waves 10326, 7 waves 10849 (SGPR spills only); the all-kinds variant spills 9 VGPRs at 7 and prefers 6.
-// Waves per SIMD the kernels are compiled for (amdgpu_waves_per_eu pins the register budget: 8 waves = 64 VGPRs, 7 = 72, 6 = 80).
-// Occupancy is what hides the latency of the dependent node gathers; measured on MI355X, one-ray-per-lane kernel, Grays/s:
+// Waves per SIMD the kernels are compiled for (amdgpu_waves_per_eu pins the register budget: 8 waves = 64 VGPRs, 7 = 72, 6 = 80;
+// unconstrained the fused variants take 84-89 VGPRs = 5 waves). Occupancy is what hides the latency of the dependent node gathers;
+// measured on MI355X, one-ray-per-lane kernel, Grays/s:
 //   1M-triangle Cornell (BVH4Q, Lambert): 6 waves 12.5, 7 waves 13.5, 8 waves 14.0 (64 VGPRs, nothing spilled);
-//   Cornell (BVH8Q, one node): 7 waves 29.9, 8 waves 25.4 — the wider node's visit does not fit 64 registers and there is no
-//   gather latency to hide; all-kinds shading (SHADE_INLINE) fits 72 registers: 7 waves (Cornell + glass + metal 25.2 -> 26.0).
+//   Cornell (BVH2, Lambert; the default layout of small scenes): 7 waves 32.8, 8 waves 34.2 (64 VGPRs, nothing spilled);
+//   BVH8Q / BVH4: the wider node's visit does not fit 64 registers (Cornell on BVH8Q: 7 waves 29.9, 8 waves 25.4);
+//   all-kinds shading (SHADE_INLINE) fits 72 registers: 7 waves; at 8 it spills 4-5 VGPRs (Cornell + glass + metal: +-0, on BVH4Q +1.7 %).
 // None of the non-counting instantiations spills or uses scratch (python tools/resources.py).
 #ifndef PT_EXT_WAVES
-#define PT_EXT_WAVES(L, FUSE) ((L) == PT_BVH_WIDTH_4Q && (FUSE) != SHADE_INLINE ? 8 : 7)
+#define PT_EXT_WAVES(L, FUSE) (((L) == PT_BVH_WIDTH_4Q || (L) == PT_BVH_WIDTH_2) && (FUSE) != SHADE_INLINE ? 8 : 7)
 #endif
 // A lane's traversal stack: kStackLds entries in its LDS column ([level][lane]: conflict-free), the rest in a global
 // overflow column sized by the builder's exact worst case (pt_bvh_info.stack_need).

@@ -178,10 +178,11 @@ def test_threads_do_not_change_the_image(P, pto):
 
 
 def test_default_layout_follows_scene_size(P, pto):
-    """PT_BVH_WIDTH_DEFAULT: BVH8Q for scenes of at most 256 triangles (a node or two, fewer dependent steps), BVH4Q above.
+    """PT_BVH_WIDTH_DEFAULT: BVH2 (float boxes) for scenes of at most 192 triangles (the whole tree is a few L1-resident lines and the
+    2-wide visit is the cheapest), BVH4Q above.
     Either way the blob validates and the oracle traversing it equals brute force (the quantised slab test of SPEC §4.1)."""
     from pathtracing_amd.host import build_bvh_detached
-    for kind, detail, want in ((P.native.PT_SCENE_CORNELL, 0, 72), (P.native.PT_SCENE_CORNELL_TESS, 3000, 68)):
+    for kind, detail, want in ((P.native.PT_SCENE_CORNELL, 0, 2), (P.native.PT_SCENE_CORNELL_TESS, 150, 2), (P.native.PT_SCENE_CORNELL_TESS, 3000, 68)):
         sd = P.make_scene(kind, detail, 5, 48, 48)
         info, nodes, tris = build_bvh_detached(sd, 0)
         assert info.width == want, (len(sd.tri_mat), info.width)
