@@ -696,8 +696,11 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
             const bool fused = !split_kernels;
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
             HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, kernel, packed_chunk, fused ? shade_mode : -1, compact,
-                                     c->bounces ? c->bounces : use_packed ? 8u : std::min(8u, std::max(4u, p->max_depth / 2u)))); // lane-packing: a lane
-                                     // pulls a new entry whenever its budget ends, so a long budget costs nothing (soup: 3.13 -> 3.23 Grays/s)
+                                     c->bounces ? c->bounces : use_packed ? (probing ? 8u : 64u) : std::min(8u, std::max(4u, p->max_depth / 2u))));
+                                     // lane-packing: a lane pulls a new entry whenever its budget ends, so a long budget costs nothing and
+                                     // saves launches (ms per frame with 8 / 16 / 32 / 64 vertices, tools/exp_packed.py: 1M soup 72.2 / 71.5 /
+                                     // 70.5 / 67.4, at 256 spp 277.6 / 271.8 / 268.3 / 266.1, 5k soup 7.99 / 7.43 / 7.35 / 7.39); the probe
+                                     // iteration keeps 8 so that it stays comparable with the one before it
             if (profile) HIP_TRY(c, hipEventRecord(e1, L.stream));
             if (!fused && !bucket_specular) HIP_TRY(c, launch_shade(L.stream, sc, pg, fp, it, L.bound, shade_mode, compact));
             else if (!fused) {
