@@ -148,8 +148,8 @@ typedef struct {
  * current values with pt_context_get_tuning, change what you want, write them back. The library reads no environment variables for
  * these (two stderr diagnostics aside: PTRT_TRACE, PTRT_TIMING). */
 typedef struct {
-    uint32_t bounces;       /* path vertices a lane advances per launch of the fused extend kernels, 1..64; 0 (default) = max_depth / 2
-                               clamped to [4, 8] for the one-ray-per-lane kernel, 64 for the lane-packing one */
+    uint32_t bounces;       /* path vertices a lane advances per launch of the fused extend kernels, 1..64; 0 (default) = 3/4 max_depth - 2
+                               clamped to [4, 12] for the one-ray-per-lane kernel, 64 for the lane-packing one */
     uint32_t loops;         /* independent shard-group wavefront loops per frame, each on its own stream: 1, 2 or 4; 0 (default) = two
                                (frames with PT_FLAG_PROFILE_KERNELS / PT_FLAG_COUNT_VISITS always run one: their kernels are timed alone) */
     uint32_t finish_below;  /* a shard with at most this many live paths runs them to their end in one launch (default 4096; 0 = never) */

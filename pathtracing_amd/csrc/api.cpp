@@ -77,8 +77,9 @@ struct pt_context {
                                                 // (PT_FLAG_PROFILE_KERNELS, visit counting, the extend-kernel probe) run one loop, so that
                                                 // a timed launch has the GPU to itself.
     uint32_t bounces = 0;                       // pt_tuning.bounces (1..64): path vertices per launch of the fused kernel (state in registers);
-                                                // 0 = max_depth / 2 clamped to [4, 8] (measured: depth 8 -> 4 is best, 12.9 vs 12.3 Grays/s at 8;
-                                                // depth 16 with glass -> 8 is best, 23.0 vs 20.6 at 4)
+                                                // 0 = 3/4 max_depth - 2 clamped to [4, 12]: depth 8 -> 4, depth 16 -> 10 (ms per frame with 2 / 3 /
+                                                // 4 / 6 / 8 / 12 vertices: 1M-triangle Cornell, depth 8: 18.57 / 17.80 / 17.52 / 17.50 / 17.68 / 17.87;
+                                                // Cornell+glass+metal, depth 16: 47.5 / 41.0 / 38.3 / 35.3 / 34.3 / 33.5)
     double compact_below = 0.9;                // pt_tuning.compact_below: a shard re-packs its queue in a launch that would leave alive/length
                                                 // below this (>1 = every launch, 0 = never); else carried in place (want_compact, kernels.hip).
     uint32_t lag = 0;                           // pt_tuning.lag (2..4; 0 = by frame length, see render_frame)
@@ -696,7 +697,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
             const bool fused = !split_kernels;
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
             HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, kernel, packed_chunk, fused ? shade_mode : -1, compact,
-                                     c->bounces ? c->bounces : use_packed ? (probing ? 8u : 64u) : std::min(8u, std::max(4u, p->max_depth / 2u))));
+                                     c->bounces ? c->bounces : use_packed ? (probing ? 8u : 64u) : std::min(12u, std::max(4u, p->max_depth * 3u / 4u - 2u))));
                                      // lane-packing: a lane pulls a new entry whenever its budget ends, so a long budget costs nothing and
                                      // saves launches (ms per frame with 8 / 16 / 32 / 64 vertices, tools/exp_packed.py: 1M soup 72.2 / 71.5 /
                                      // 70.5 / 67.4, at 256 spp 277.6 / 271.8 / 268.3 / 266.1, 5k soup 7.99 / 7.43 / 7.35 / 7.39); the probe
