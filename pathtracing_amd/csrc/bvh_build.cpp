@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace ptrt {
 namespace {
@@ -54,7 +55,13 @@ struct Builder {
     std::vector<uint32_t> &idx;
     std::vector<Tmp> nodes;
     uint32_t max_leaf = kMaxLeaf; // 1: every primitive its own leaf (the top-level build over LBVH clusters)
-    Builder(const std::vector<Prim> &p, std::vector<uint32_t> &i) : prims(p), idx(i) { nodes.reserve(p.size()); }
+    // Parallel build: ranges of more than `defer_above` primitives that reach depth `defer_depth` are not built but recorded in
+    // `deferred` (a placeholder node holds their place); build_parallel() builds them on their own threads and splices them in.
+    int defer_depth = -1; uint32_t defer_above = 0;
+    struct Deferred { int32_t node; uint32_t b, e; int depth; };
+    std::vector<Deferred> deferred;
+    Builder(const std::vector<Prim> &p, std::vector<uint32_t> &i, size_t reserve) : prims(p), idx(i) { nodes.reserve(reserve); }
+    Builder(const std::vector<Prim> &p, std::vector<uint32_t> &i) : Builder(p, i, p.size()) {}
 
     int32_t make_leaf(uint32_t b, uint32_t e, const Box &box)
     {
@@ -66,6 +73,11 @@ struct Builder {
     int32_t build(uint32_t b, uint32_t e, int depth)
     {
         const uint32_t n = e - b;
+        if (depth == defer_depth && n > defer_above) {
+            nodes.push_back(Tmp{});
+            deferred.push_back(Deferred{ (int32_t)nodes.size() - 1, b, e, depth });
+            return (int32_t)nodes.size() - 1;
+        }
         Box box, cb;
         box.reset(); cb.reset();
         for (uint32_t i = b; i < e; ++i) { box.grow(prims[idx[i]].box); cb.grow(prims[idx[i]].c); }
@@ -130,6 +142,38 @@ struct Builder {
         return me;
     }
 };
+
+// The same tree as Builder::build(0, n, 0), built on several threads: the top levels serially down to depth `kParDepth`, every
+// big range found there on a thread of its own (disjoint ranges of `idx`, a private node vector each), then spliced behind the top
+// part with the indices shifted. Splits depend only on a range's own primitives, so the topology — and with it the emitted blob
+// — is the serial one; only the order of the nodes in `nodes` differs, which nothing reads.
+constexpr int kParDepth = 4;
+int32_t build_parallel(Builder &B, uint32_t n)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (n < (1u << 16) || hw < 2) return B.build(0, n, 0);
+    B.defer_depth = kParDepth; B.defer_above = 4096;
+    const int32_t root = B.build(0, n, 0);
+    B.defer_depth = -1;
+    const std::vector<Builder::Deferred> jobs = B.deferred;
+    std::vector<Builder> subs;
+    subs.reserve(jobs.size());
+    for (const auto &j : jobs) { subs.emplace_back(B.prims, B.idx, (size_t)(j.e - j.b)); subs.back().max_leaf = B.max_leaf; }
+    std::vector<int32_t> roots(jobs.size(), 0);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < jobs.size(); ++k)
+        th.emplace_back([&, k] { roots[k] = subs[k].build(jobs[k].b, jobs[k].e, jobs[k].depth); });
+    for (auto &t : th) t.join();
+    for (size_t k = 0; k < jobs.size(); ++k) {
+        const int32_t off = (int32_t)B.nodes.size();
+        for (Tmp t : subs[k].nodes) {
+            if (!t.count) { t.left += off; t.right += off; }
+            B.nodes.push_back(t);
+        }
+        B.nodes[(size_t)jobs[k].node] = B.nodes[(size_t)(off + roots[k])]; // the placeholder becomes the subtree's root (children already shifted)
+    }
+    return root;
+}
 
 // Binary tree (tmp nodes, leaves = ranges of idx) -> blob: collapse to `width` children per node by opening the child of
 // largest area, lay nodes out breadth-first, emit triangles in leaf order, compute depth and the worst-case stack need.
@@ -229,7 +273,7 @@ void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint3
         idx[i] = i;
     }
     Builder B(prims, idx);
-    const int32_t root = B.build(0, n_tris, 0);
+    const int32_t root = build_parallel(B, n_tris);
     emit_blob(B.nodes, root, idx, verts9, mats, n_tris, width, out);
     out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
