@@ -221,3 +221,27 @@ def test_quantised_slab_test_is_conservative_on_grazing_rays(P, pto):
         s = pto.Scene(sd, (width, nodes, tris))
         for o, d in rays:
             assert s.closest(o, d) == brute.closest(o, d)
+
+
+def test_threaded_sah_build_is_the_serial_tree(P):
+    """The host builder builds the subtrees below depth 4 on threads (bvh_build.cpp build_parallel): the blob must be the serial one,
+    byte for byte. The serial reference comes from a child process pinned to one CPU (std::thread::hardware_concurrency() == 1)."""
+    import hashlib, subprocess, sys, textwrap
+    if len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("one CPU: the build is serial anyway")
+    code = textwrap.dedent("""
+        import os, sys, hashlib
+        if sys.argv[1] == "serial": os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+        sys.path.insert(0, %r)
+        import numpy as np
+        import pathtracing_amd as P
+        from pathtracing_amd.host import build_bvh_detached
+        for kind, detail in ((P.native.PT_SCENE_TRIANGLE_SOUP, 90000), (P.native.PT_SCENE_CORNELL_TESS, 120000)):
+            sd = P.make_scene(kind, detail, 11, 32, 32)
+            for width in (68, 2):
+                info, nodes, tris = build_bvh_detached(sd, width)
+                print(info.n_nodes, info.max_depth, info.stack_need, hashlib.md5(np.asarray(nodes).tobytes() + np.asarray(tris).tobytes()).hexdigest())
+        """) % os.path.dirname(HERE)
+    outs = [subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=600) for mode in ("serial", "threads")]
+    assert all(o.returncode == 0 for o in outs), outs[0].stderr[-500:] + outs[1].stderr[-500:]
+    assert outs[0].stdout == outs[1].stdout and len(outs[0].stdout.splitlines()) == 4
