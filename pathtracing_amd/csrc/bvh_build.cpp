@@ -148,11 +148,11 @@ struct Builder {
 // part with the indices shifted. Splits depend only on a range's own primitives, so the topology — and with it the emitted blob
 // — is the serial one; only the order of the nodes in `nodes` differs, which nothing reads.
 constexpr int kParDepth = 4;
-int32_t build_parallel(Builder &B, uint32_t n)
+int32_t build_parallel(Builder &B, uint32_t n, uint32_t serial_below = 1u << 16, uint32_t defer_above = 4096)
 {
     const unsigned hw = std::thread::hardware_concurrency();
-    if (n < (1u << 16) || hw < 2) return B.build(0, n, 0);
-    B.defer_depth = kParDepth; B.defer_above = 4096;
+    if (n < serial_below || hw < 2) return B.build(0, n, 0);
+    B.defer_depth = kParDepth; B.defer_above = defer_above;
     const int32_t root = B.build(0, n, 0);
     B.defer_depth = -1;
     const std::vector<Builder::Deferred> jobs = B.deferred;
@@ -280,12 +280,12 @@ void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint3
 
 // A binary LBVH built on the device (lbvh.hip) -> blob, in two storeys:
 //   top    : the LBVH is cut where a subtree holds at most kClusterTris triangles; the host's binned-SAH builder makes a binary tree
-//            over those clusters (a few thousand boxes: milliseconds). Every ray crosses the top levels, and Morton splits are at
+//            over those clusters (65 k boxes for 1M triangles, built on threads: a few milliseconds). Every ray crosses the top levels, and Morton splits are at
 //            their worst there (1M-triangle Cornell: 9.15 -> 7.9 node visits per ray).
 //   bottom : inside a cluster the device's topology and boxes are kept; subtrees of at most kMaxLeaf triangles become leaves unless
 //            splitting them lowers the SAH cost — the leaf rule of Builder::build (their triangles are contiguous in Morton order).
 #ifndef PT_LBVH_CLUSTER
-#define PT_LBVH_CLUSTER 128
+#define PT_LBVH_CLUSTER 32
 #endif
 constexpr uint32_t kClusterTris = PT_LBVH_CLUSTER; // 0: no SAH storey, the LBVH as it is
 void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out)
@@ -371,7 +371,7 @@ void build_sah_over_boxes(const float *boxes6, uint32_t n, std::vector<int32_t> 
     }
     Builder b(prims, idx);
     b.max_leaf = 1;
-    const int32_t r = b.build(0, n, 0);
+    const int32_t r = build_parallel(b, n, 8192, 256);
     // internal Tmp nodes -> compact internal numbering; leaves -> ~box index
     std::vector<int32_t> number(b.nodes.size(), -1);
     int32_t n_int = 0;
@@ -400,7 +400,8 @@ static void quantize_nodes(const BvhBlob &in, std::vector<uint8_t> &out)
 {
     constexpr size_t kStride = N == 4 ? 64 : 128, kQ = 16 + 4 * N; // quantised coordinates start after origin|exps and the refs
     out.assign((size_t)in.n_nodes * kStride, 0);
-    for (uint32_t i = 0; i < in.n_nodes; ++i) {
+    auto range = [&](uint32_t i0, uint32_t i1) { // nodes are independent of one another
+    for (uint32_t i = i0; i < i1; ++i) {
         const BvhSlot *s = &in.slots[(size_t)i * N];
         uint8_t *nd = &out[(size_t)i * kStride];
         float org[3]; uint8_t ex[3];
@@ -439,6 +440,12 @@ static void quantize_nodes(const BvhBlob &in, std::vector<uint8_t> &out)
         for (int c = 0; c < N; ++c) std::memcpy(nd + 16 + 4 * c, &s[c].ref, 4);
         for (int k = 0; k < 3; ++k) { std::memcpy(nd + kQ + N * k, qlo[k], N); std::memcpy(nd + kQ + N * (3 + k), qhi[k], N); }
     }
+    };
+    const uint32_t nt = in.n_nodes < (1u << 15) ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (nt == 1) { range(0, in.n_nodes); return; }
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nt; ++t) th.emplace_back(range, (uint32_t)((uint64_t)in.n_nodes * t / nt), (uint32_t)((uint64_t)in.n_nodes * (t + 1) / nt));
+    for (auto &t : th) t.join();
 }
 
 void quantize_bvh4(const BvhBlob &in, std::vector<uint8_t> &out) { quantize_nodes<4>(in, out); }

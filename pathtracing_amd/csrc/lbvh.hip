@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) k_tri_records(const float *__restrict__ v
 } // namespace
 
 #ifndef PT_LBVH_CLUSTER
-#define PT_LBVH_CLUSTER 128
+#define PT_LBVH_CLUSTER 32
 #endif
 
 hipError_t build_lbvh_device(hipStream_t stream, const float *verts9, uint32_t n, BinaryBvh &out)
