@@ -435,7 +435,7 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     }
     if (s->node_bytes()) HIP_TRY(c, hipMemcpy(s->d_nodes.p, s->node_data(), s->node_bytes(), hipMemcpyHostToDevice));
     }
-    HIP_TRY(c, s->d_spheres.ensure(ns));
+    HIP_TRY(c, s->d_spheres.ensure((ns + 3u) & ~3u)); // the kernels read the list four spheres (one 64-byte scalar load) at a time
     HIP_TRY(c, s->d_sph_mat.ensure(ns));
     HIP_TRY(c, s->d_mats.ensure((size_t)nm * 3));
     if (ns) {

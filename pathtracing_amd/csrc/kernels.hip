@@ -32,6 +32,28 @@ namespace ptrt {
 
 PT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// Scene data that no kernel writes, read at a wave-uniform address: through the constant address space the load is a scalar
+// load (s_load_dwordx4 into SGPRs, scalar cache) instead of a vector load whose 64 lanes fetch the same 16 bytes — for the sphere
+// list that is 4 vector-memory round trips less per ray, each of which the wave used to wait for.
+typedef const float4 __attribute__((address_space(4))) *uniform_f4;
+PT_DEV uniform_f4 as_uniform(const float4 *p) { return (uniform_f4)(uintptr_t)p; }
+PT_DEV float4 uniform_load(uniform_f4 p, uint32_t i) { return make_float4(p[i].x, p[i].y, p[i].z, p[i].w); }
+// The sphere list against one ray, in list order (docs/SPEC.md: ties go to the lower primitive id, and a later sphere never replaces
+// an equal hit): four spheres per 64-byte scalar load (api.cpp pads the array to a multiple of four entries), tests of the ones
+// that exist. Returns the number of tests.
+PT_DEV uint32_t spheres_test(const float4 *spheres, uint32_t n_spheres, uint32_t first_id, V3 o, V3 d, Hit &h)
+{
+    const uniform_f4 sp = as_uniform(spheres);
+    for (uint32_t j = 0; j < n_spheres; j += 4u) {
+        const float4 s0 = uniform_load(sp, j), s1 = uniform_load(sp, j + 1u), s2 = uniform_load(sp, j + 2u), s3 = uniform_load(sp, j + 3u);
+        sphere_test(s0, first_id + j, o, d, h);
+        if (j + 1u < n_spheres) sphere_test(s1, first_id + j + 1u, o, d, h);
+        if (j + 2u < n_spheres) sphere_test(s2, first_id + j + 2u, o, d, h);
+        if (j + 3u < n_spheres) sphere_test(s3, first_id + j + 3u, o, d, h);
+    }
+    return n_spheres;
+}
+
 // Append `value` of every lane with `pred` to queue: one ballot, one atomic per wavefront, mbcnt prefix.
 // Must be reached by all live lanes of the wave in uniform control flow.
 PT_DEV void wave_push(uint32_t *counter, uint32_t *queue, bool pred, uint32_t value)
@@ -655,10 +677,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
             asm volatile("" ::: "memory"); // the values must really leave the registers: no store-to-load forwarding across the traversal
         }
 
-        for (uint32_t j = 0; j < n_spheres; ++j) { // uniform index => scalar loads
-            sphere_test(spheres[j], n_tris + j, o, d, h);
-            if (COUNT) c_sph++;
-        }
+        { const uint32_t ns = spheres_test(spheres, n_spheres, n_tris, o, d, h); if (COUNT) c_sph += ns; }
 
         const RaySetup rs = ray_setup(o, d);
         int32_t cur = n_nodes ? 0 : PT_BVH_EMPTY;
@@ -813,10 +832,7 @@ k_extend_packed(ExtArgs a)
             asm volatile("" ::: "memory"); // no store-to-load forwarding: the values leave the registers
         }
         h = Hit{ __builtin_inff(), PT_MISS, PT_MISS };
-        for (uint32_t j = 0; j < n_spheres; ++j) {
-            sphere_test(spheres[j], n_tris + j, o, d, h);
-            if (COUNT) c_sph++;
-        }
+        { const uint32_t ns = spheres_test(spheres, n_spheres, n_tris, o, d, h); if (COUNT) c_sph += ns; }
         rs = ray_setup(o, d);
         cur = n_nodes ? 0 : PT_BVH_EMPTY;
         sp = 0; steps = 0;
@@ -1001,7 +1017,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_POOL
 
     auto spheres_of = [&](V3 o, V3 d, uint32_t e) { // the sphere list is tested when a ray is made (full width); traversal starts from its result
         Hit h{ __builtin_inff(), PT_MISS, PT_MISS };
-        for (uint32_t j = 0; j < n_spheres; ++j) sphere_test(spheres[j], n_tris + j, o, d, h); // uniform index => scalar loads
+        spheres_test(spheres, n_spheres, n_tris, o, d, h);
         s_ht[e] = h.t; s_href[e] = h.ref;
     };
     auto live_append = [&](bool pred, uint32_t e, uint32_t &count) {
