@@ -522,7 +522,8 @@ PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint
 //   Cornell (BVH2, Lambert; the default layout of small scenes): 7 waves 32.8, 8 waves 34.2 (64 VGPRs, nothing spilled);
 //   BVH8Q / BVH4: the wider node's visit does not fit 64 registers (Cornell on BVH8Q: 7 waves 29.9, 8 waves 25.4);
 //   all-kinds shading (SHADE_INLINE) fits 72 registers: 7 waves; at 8 it spills 4-5 VGPRs (Cornell + glass + metal: +-0, on BVH4Q +1.7 %).
-// None of the non-counting instantiations spills or uses scratch (python tools/resources.py).
+// None of the non-counting k_extend instantiations spills a VGPR or uses scratch (python tools/resources.py); k_extend<BVH2, Lambert>
+// keeps 2 SGPRs in VGPR lanes since the root's rows pass through SGPRs.
 #ifndef PT_EXT_WAVES
 #define PT_EXT_WAVES(L, FUSE) (((L) == PT_BVH_WIDTH_4Q || (L) == PT_BVH_WIDTH_2) && (FUSE) != SHADE_INLINE ? 8 : 7)
 #endif
@@ -554,11 +555,20 @@ PT_DEV int32_t pop_slow(const StackCtx &k, uint32_t &sp)
 // (the common case), a push is an unconditional LDS store plus a predicated increment and a pop is a plain LDS load — no
 // LDS-or-spill branch per push.
 template <int L>
+PT_DEV void node_visit_rows(const float4 *__restrict__ base, float4 r0, float4 r1, float4 r2, float4 r3, const StackCtx &k, const RaySetup &rs,
+                            float t_best, int32_t &cur, uint32_t &sp);
+template <int L>
 PT_DEV void node_step(const float4 *__restrict__ nodes, const StackCtx &k, const RaySetup &rs, float t_best, int32_t &cur, uint32_t &sp)
 {
-    constexpr int N = fanout<L>();
     const float4 *base = nodes + (size_t)cur * node_rows<L>();
-    const float4 r0 = base[0], r1 = base[1], r2 = base[2], r3 = base[3];
+    node_visit_rows<L>(base, base[0], base[1], base[2], base[3], k, rs, t_best, cur, sp);
+}
+// The visit of the node whose first four rows are r0..r3 (`base`: where layouts with more rows find the rest).
+template <int L>
+PT_DEV void node_visit_rows(const float4 *__restrict__ base, float4 r0, float4 r1, float4 r2, float4 r3, const StackCtx &k, const RaySetup &rs,
+                            float t_best, int32_t &cur, uint32_t &sp)
+{
+    constexpr int N = fanout<L>();
     const bool deep = __any((int)(sp + (uint32_t)(N - 1) > kStackLds)) != 0;
     uint32_t key[N];
     int32_t ref[N];
@@ -682,6 +692,16 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
         const RaySetup rs = ray_setup(o, d);
         int32_t cur = n_nodes ? 0 : PT_BVH_EMPTY;
         uint32_t sp = 0, steps = 0;
+        // Every ray starts at node 0, whose rows are the same for the whole wave: this first visit reads them with one scalar load
+        // (no vector gather to wait for) and runs at full width before the divergent node loop (headline 17.03 -> 16.88 ms, Cornell
+        // 7.31 -> 7.02, Cornell+glass+metal 32.6 -> 31.9).
+        if (n_nodes) {
+            ++steps;
+            if (COUNT) { c_nodes++; if (lane_id() == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) c_wave_iters++; }
+            const uniform_f4 root = as_uniform(nodes);
+            node_visit_rows<L>(nodes, uniform_load(root, 0), uniform_load(root, 1), uniform_load(root, 2), uniform_load(root, 3), stk, rs, h.t, cur, sp);
+            if (COUNT) s_state[tid & 63u] = cur;
+        }
 
         // while-while: a lane that reaches a leaf waits at the reconvergence point of the node loop until every lane of
         // the wave is at a leaf or done; then the leaves are tested together. Each lane still makes exactly the visits,
