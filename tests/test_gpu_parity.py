@@ -618,3 +618,23 @@ def test_randomised_configurations_against_the_oracle(P, pto, renderer):
                 assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests), ctx
     finally:
         renderer.SetTuning(**{k: getattr(defaults, k) for k in ("bounces", "loops", "finish_below", "packed_chunk", "compact_below", "sparse_below", "sticky_samples", "lag")})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [8, 4])  # one ray per lane, lane-packing
+def test_sphere_lists_of_any_length(P, pto, renderer, flags):
+    """The kernels read the sphere list four spheres per scalar load (device arrays padded to a multiple of four): lists of
+    0, 1, 2, 3, 5, 6 and 9 spheres must give the oracle's frame, ray count and sphere-test count."""
+    base = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 3, 160, 120)
+    rng = np.random.default_rng(5)
+    pool = np.concatenate([base.spheres] + [base.spheres * np.float32([1, 1, 1, 0.6]) + np.float32([dx, 0.35 * (k + 1), dz, 0]) for k, (dx, dz) in
+                                            enumerate(rng.uniform(-0.15, 0.15, (2, 2)))])[:9].astype(np.float32)
+    pool_mat = np.concatenate([base.sph_mat] * 3)[:9].astype(np.uint32)
+    for n in (0, 1, 2, 3, 5, 6, 9):
+        sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 3, 160, 120)
+        sd.spheres, sd.sph_mat = pool[:n].copy(), pool_mat[:n].copy()
+        p = P.make_params(160, 120, spp=6, max_depth=10, streams=2, flags=flags)
+        img, st, ref, ost = run_both(P, pto, renderer, sd, p, 0, count=True)
+        assert st.rays == ost.rays and np.array_equal(img, ref), n
+        assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests), n
+        assert st.sphere_tests == n * st.rays
