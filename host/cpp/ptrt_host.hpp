@@ -32,6 +32,8 @@ public:
 
     void Init(int device = 0) // Renderer.Init, Renderer.cs:66-84
     {
+        if (pt_abi_version() != PTRT_ABI_VERSION) // the library found at run time is not the one this header describes
+            throw Error(PT_ERR_UNSUPPORTED, "libptrt has ABI version " + std::to_string(pt_abi_version()) + ", built against " + std::to_string(PTRT_ABI_VERSION));
         pt_device_desc d{}; d.device_ordinal = device;
         check(pt_context_create(&d, &ctx_));
     }

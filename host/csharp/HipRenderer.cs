@@ -23,6 +23,7 @@ public unsafe class HipRenderer : IDisposable
     // Renderer.Init (Renderer.cs:66-84): device + resources + compute pipeline
     public void Init(int device = 0)
     {
+        if (Ptrt.pt_abi_version() != Ptrt.AbiVersion) throw new Exception($"libptrt has ABI version {Ptrt.pt_abi_version()}, this binding expects {Ptrt.AbiVersion}");
         PtDeviceDesc d = new() { device_ordinal = device };
         void* c; Ptrt.Check(Ptrt.pt_context_create(&d, &c)); _ctx = c;
     }

@@ -27,7 +27,7 @@ public enum PtBvhWidth : uint { Default = 0, W2 = 2, W4 = 4, W4Q = 68, W8Q = 72,
     public ulong rays; public ulong paths; public ulong node_visits; public ulong tri_tests; public ulong sphere_tests; public uint iterations; public uint extend_launches;
     public double gpu_ms; public double extend_ms; public double shade_ms; public double other_ms; public fixed ulong reserved[4];
 }
-[StructLayout(LayoutKind.Sequential)] public unsafe struct PtTuning { public uint bounces; public uint loops; public uint finish_below; public uint packed_chunk; public float compact_below; public float sparse_below; public uint sticky_samples; public uint lag; }
+[StructLayout(LayoutKind.Sequential)] public unsafe struct PtTuning { public uint bounces; public uint loops; public uint finish_below; public uint packed_chunk; public float compact_below; public float sparse_below; public uint sticky_samples; public uint lag; public uint extend_kernel; public uint readback; }
 [StructLayout(LayoutKind.Sequential)] public struct PtBvhInfo
 {
     public uint width; public uint n_nodes; public uint n_tris; public uint max_depth; public ulong node_bytes; public ulong tri_bytes; public double build_ms; public float sah_cost; public uint stack_need;
@@ -38,6 +38,7 @@ public enum PtBvhWidth : uint { Default = 0, W2 = 2, W4 = 4, W4Q = 68, W8Q = 72,
 public static unsafe class Ptrt
 {
     private const string Lib = "ptrt"; // libptrt.so next to the executable or on LD_LIBRARY_PATH
+    public const uint AbiVersion = 2;  // PTRT_ABI_VERSION of the include/ptrt.h this file mirrors; HipRenderer.Init compares it with pt_abi_version()
 
     [DllImport(Lib)] public static extern uint pt_abi_version();
     [DllImport(Lib)] public static extern PtStatus pt_context_create(PtDeviceDesc* desc, void** ctx);

@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define PTRT_ABI_VERSION 1
+/* 2: pt_tuning grew to 40 bytes (extend_kernel, readback); pt_comm_*, pt_framebuffer_read_srgb8, PT_FLAG_EXTEND_POOL, pt_bvh_info.stack_need and
+ * the BVH2 default for small scenes had arrived under version 1. Hosts compare pt_abi_version() with the header they were built against. */
+#define PTRT_ABI_VERSION 2
 
 typedef int32_t pt_status;
 enum {
@@ -117,8 +119,9 @@ typedef struct {
     uint64_t rays;          /* ray-scene intersection queries = path segments (the benchmark's unit) */
     uint64_t paths;
     uint64_t node_visits, tri_tests, sphere_tests; /* only with PT_FLAG_COUNT_VISITS, else 0 */
-    uint32_t iterations;    /* wavefront iterations = launches of the extend kernel; the default (fused) kernel advances every
-                               path by up to max_depth / 2 clamped to [4, 8] vertices per iteration (pt_tuning.bounces overrides) */
+    uint32_t iterations;    /* wavefront iterations = launches of the extend kernel; the default (fused one-ray-per-lane) kernel advances
+                               every path by up to 3/4 max_depth - 2 clamped to [4, 12] vertices per iteration, the lane-packing one by up
+                               to 64 (pt_tuning.bounces overrides) */
     uint32_t extend_launches;
     double gpu_ms;          /* hipEvent start->stop around all kernels of the frame */
     double extend_ms;       /* sum of extend-kernel durations (PT_FLAG_PROFILE_KERNELS); includes shading when fused */
@@ -137,7 +140,8 @@ typedef struct {
     uint32_t n_tris;
     uint32_t max_depth;
     uint64_t node_bytes;     /* n_nodes * 64 (layouts 2 and 4Q) or n_nodes * 128 (layouts 4 and 8Q) */
-    uint64_t tri_bytes;      /* n_tris * 48 */
+    uint64_t tri_bytes;      /* n_tris * 48: the blob's triangle records as pt_scene_bvh_read copies them out (docs/SPEC.md §4.1). On the device
+                                every record is padded to one 64-byte line (+ a shading row): n_tris * 64 bytes of HBM */
     double build_ms;
     float sah_cost;
     uint32_t stack_need;     /* worst-case traversal-stack depth of this tree (entries); the kernels keep 12 per lane in LDS and
@@ -159,9 +163,15 @@ typedef struct {
     float sparse_below;     /* one-ray-per-lane kernel: a launch that starts with alive < this * length advances one vertex only (default 0 = off) */
     uint32_t sticky_samples; /* frames with at most this many samples per stream (spp / streams): a shard that has re-packed once re-packs
                                in every launch, and with at most 2 samples per stream every launch re-packs (default 32; 0 = off) */
-    uint32_t lag;           /* wavefront iterations the host runs ahead of the queue sizes it reads back: 2, 3 or 4; 0 (default) = 2 for
-                               frames of at most 2 samples per stream, else 3 */
-} pt_tuning; /* 32 B */
+    uint32_t lag;           /* wavefront iterations the host runs ahead of the queue sizes it reads back: 2..5; 0 (default) = 3 for frames
+                               of at most 2 samples per stream, else 4 (one less each with readback = 1) */
+    uint32_t extend_kernel; /* 0 (default) = the extend kernel is probed per scene (timed, remembered in the scene; pt_stats.reserved[0]
+                               tells which one ran); 1 / 2 / 3 = every frame uses the one-ray-per-lane / lane-packing / pooled kernel, so
+                               that runs are reproducible in speed as well as in pixels. A PT_FLAG_EXTEND_* of a frame overrides it */
+    uint32_t readback;      /* how a launch's queue sizes reach the host: 0 (default) = the next launch's first thread per shard stores them
+                               to host-mapped pinned memory; 1 = a 2-4 KB device-to-host copy behind every launch (a copy dispatch
+                               that sits in order between two launches: rounds 1-2) */
+} pt_tuning; /* 40 B */
 
 /* ---- context: replaces GraphicsDevice.Init (GraphicsDevice.cs:38-43) + Renderer.CreateResources (Renderer.cs:105-196) */
 pt_status pt_context_create(const pt_device_desc *desc, pt_context **out);
@@ -227,7 +237,7 @@ enum { PT_COMM_FORCE_RCCL = 1u }; /* pt_comm_create flags: use the RCCL path eve
 /* ctxs[i] renders rank i of n_ranks; the assembled frame lands in ctxs[root] (pt_framebuffer_read*). Either every rank has its own
  * context on its own device, or all ranks share one context. */
 pt_status pt_comm_create(pt_context *const *ctxs, uint32_t n_ranks, uint32_t root, uint32_t flags, pt_comm **out);
-void pt_comm_destroy(pt_comm *comm);
+void pt_comm_destroy(pt_comm *comm); /* before or after its contexts: every pt_comm call returns with nothing in flight */
 /* One frame: rank i renders its tiles of `params` (rank / nranks are filled in) on scenes[i] — the same scene committed on every
  * context — concurrently (one host thread per context), then the tiles are gathered to the root and assembled there.
  * stats: n_ranks entries or NULL. Synchronous, like pt_render. */

@@ -77,7 +77,8 @@ class pt_bvh_info(C.Structure):
 
 class pt_tuning(C.Structure):
     _fields_ = [("bounces", C.c_uint32), ("loops", C.c_uint32), ("finish_below", C.c_uint32), ("packed_chunk", C.c_uint32),
-                ("compact_below", C.c_float), ("sparse_below", C.c_float), ("sticky_samples", C.c_uint32), ("lag", C.c_uint32)]
+                ("compact_below", C.c_float), ("sparse_below", C.c_float), ("sticky_samples", C.c_uint32), ("lag", C.c_uint32),
+                ("extend_kernel", C.c_uint32), ("readback", C.c_uint32)]
 
 
 class pt_tile_layout(C.Structure):
@@ -89,7 +90,7 @@ class pt_scene_counts(C.Structure):
     _fields_ = [("n_tris", C.c_uint64), ("n_spheres", C.c_uint64), ("n_mats", C.c_uint64)]
 
 
-assert C.sizeof(pt_material) == 48 and C.sizeof(pt_camera) == 64 and C.sizeof(pt_render_params) == 64 and C.sizeof(pt_tuning) == 32
+assert C.sizeof(pt_material) == 48 and C.sizeof(pt_camera) == 64 and C.sizeof(pt_render_params) == 64 and C.sizeof(pt_tuning) == 40
 
 _vp, _u32, _u64, _st = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
 _P = C.POINTER
@@ -132,3 +133,7 @@ for _name, (_res, _args) in SYMBOLS.items():
     _f = getattr(lib, _name)  # AttributeError here = the library does not export what the header declares
     _f.restype = _res
     _f.argtypes = _args
+
+PTRT_ABI_VERSION = 2  # include/ptrt.h this binding was written against
+if lib.pt_abi_version() != PTRT_ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} has ABI version {lib.pt_abi_version()}, this binding expects {PTRT_ABI_VERSION}: rebuild libptrt.so")

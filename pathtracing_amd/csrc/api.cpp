@@ -22,7 +22,7 @@ namespace {
 
 thread_local std::string g_err;
 
-constexpr uint32_t kLag = 4; // most wavefront iterations kept in flight before the host looks at a queue size (ring sizes; pt_tuning.lag)
+constexpr uint32_t kLag = 5; // most wavefront iterations kept in flight before the host looks at a queue size (ring sizes; pt_tuning.lag)
 constexpr uint32_t kRingWords = kShards * kCounterStride; // one iteration's readback: (up to) the kShards extend-queue sizes
 constexpr uint32_t kMaxGroups = 4;  // independent wavefront loops (shard groups) per frame, each on its own stream
 constexpr size_t kFinalOffset = (size_t)kMaxGroups * kLag * kRingWords; // where the frame-end copy of all counters lands in h_counts
@@ -66,7 +66,11 @@ struct pt_context {
     DevBuf<float2> hit;
     DevBuf<uint32_t> sd, q_ext0, q_ext1, q_b[B_COUNT], counters, fb8;
     DevBuf<int32_t> stack_ovf;
-    uint32_t *h_counts = nullptr; // pinned: kLag readbacks of the per-shard queue sizes + one copy of all counters
+    uint32_t *h_counts = nullptr; // pinned: kLag readbacks of the per-shard queue sizes (pt_tuning.readback = 1) + one copy of all counters
+    uint4 *h_ring = nullptr, *d_ring = nullptr; // mapped pinned memory the extend kernels report their queue sizes to, kLag x kShards lines
+                                                // (host address, device address); PathState::host_ring
+    uint32_t readback = 0;                      // pt_tuning.readback: 0 = the kernels store the sizes to h_ring, 1 = one 2-4 KB copy per launch
+    uint32_t extend_kernel = 0;                 // pt_tuning.extend_kernel: 0 = probed per scene, else the ExtendKernel every scene uses
     hipEvent_t ev_lag[kMaxGroups][kLag] = {};
     hipStream_t group_stream[kMaxGroups] = {}; // group 0 runs on `stream` when there is one group only
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups] = {};
@@ -121,6 +125,8 @@ struct pt_scene {
     bool has_specular = false;
     mutable uint32_t ext_choice = 0;     // cache, not scene content: the extend kernel an earlier frame's probe picked (0 = none yet, ExtendKernel otherwise)
     mutable double rate_simple = 0.0, rate_packed = 0.0; // rays per ms of whole frames run on one kernel (frames too short to probe inside)
+    mutable uint32_t probe_misses = 0;   // warm frames that neither decided nor fed the decision (too few rays to time): after three the scene
+                                         // settles on the one-ray-per-lane kernel instead of staying in probe mode (one loop, no finish mode) for good
     DevBuf<uint32_t> d_sph_mat;
     DeviceScene ds{};
 };
@@ -211,6 +217,9 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
         c->own_stream = true;
     }
     bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * (kFinalOffset + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_ring, sizeof(uint4) * kLag * kShards, hipHostMallocMapped) == hipSuccess &&
+         hipHostGetDevicePointer((void **)&c->d_ring, c->h_ring, 0) == hipSuccess;
+    if (ok) std::memset(c->h_ring, 0, sizeof(uint4) * kLag * kShards);
     for (uint32_t g = 0; ok && g < kMaxGroups; ++g) {
         ok = hipStreamCreateWithFlags(&c->group_stream[g], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) == hipSuccess;
@@ -232,6 +241,7 @@ pt_status pt_context_get_tuning(const pt_context *c, pt_tuning *o)
     std::memset(o, 0, sizeof *o);
     o->bounces = c->bounces; o->loops = c->groups; o->finish_below = c->finish_below; o->packed_chunk = c->packed_chunk;
     o->compact_below = (float)c->compact_below; o->sparse_below = (float)c->sparse_below; o->sticky_samples = c->sticky_samples; o->lag = c->lag;
+    o->extend_kernel = c->extend_kernel; o->readback = c->readback;
     return PT_OK;
 }
 
@@ -245,7 +255,10 @@ pt_status pt_context_set_tuning(pt_context *c, const pt_tuning *t)
     if (!(t->compact_below >= 0.f && t->compact_below <= 2.f) || !(t->sparse_below >= 0.f && t->sparse_below <= 1.f))
         return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: compact_below must be in [0,2], sparse_below in [0,1]");
     c->bounces = t->bounces; c->groups = t->loops; c->finish_below = t->finish_below; c->packed_chunk = t->packed_chunk;
+    if (t->extend_kernel > (uint32_t)EXT_POOL) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: extend_kernel must be 0 (probed), 1 (one ray per lane), 2 (lane-packing) or 3 (pooled)");
+    if (t->readback > 1) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: readback must be 0 (mapped store) or 1 (copy per launch)");
     c->compact_below = t->compact_below; c->sparse_below = t->sparse_below; c->sticky_samples = t->sticky_samples; c->lag = t->lag;
+    c->extend_kernel = t->extend_kernel; c->readback = t->readback;
     return PT_OK;
 }
 
@@ -259,6 +272,7 @@ void pt_context_destroy(pt_context *c)
     c->sd.release(); c->q_ext0.release(); c->q_ext1.release(); c->counters.release(); c->fb8.release(); c->stack_ovf.release();
     for (auto &q : c->q_b) q.release();
     if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
     for (auto &row : c->ev_lag) for (auto &e : row) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_join) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -451,7 +465,7 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     for (int k = 0; k < 3; ++k) d.sky[k] = s->sky[k];
     d.bvh_width = bvh_width;
     d.cam = s->cam;
-    s->ext_choice = 0; s->rate_simple = s->rate_packed = 0.0;
+    s->ext_choice = 0; s->rate_simple = s->rate_packed = 0.0; s->probe_misses = 0;
     s->has_specular = false;
     for (const pt_material &m : s->mats) if (m.kind != PT_LAMBERT) s->has_specular = true;
     s->committed = true;
@@ -542,7 +556,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     const bool bucket_specular = (p->flags & PT_FLAG_BUCKET_SPECULAR) != 0;
     const bool split_kernels = bucket_specular || (p->flags & PT_FLAG_SPLIT_KERNELS) != 0;
     const uint32_t forced_choice = (p->flags & PT_FLAG_EXTEND_POOL) ? (uint32_t)EXT_POOL : (p->flags & PT_FLAG_EXTEND_PACKED) ? (uint32_t)EXT_PACKED
-                                   : (p->flags & PT_FLAG_EXTEND_SIMPLE) ? (uint32_t)EXT_SIMPLE : 0u;
+                                   : (p->flags & PT_FLAG_EXTEND_SIMPLE) ? (uint32_t)EXT_SIMPLE : c->extend_kernel; // a flag beats pt_tuning.extend_kernel
 
     if (p->mode == PT_REFERENCE_SPHERE) {
         // Renderer.ComputeFrame: one dispatch, then the host blocks on the fence (Renderer.cs:1020,1036,972)
@@ -596,6 +610,8 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     ps.compact_below = (float)c->compact_below; ps.finish_below = c->finish_below; ps.sparse_below = (float)c->sparse_below;
     const uint32_t samples_per_stream = (p->spp + (p->streams ? p->streams : 1u) - 1u) / (p->streams ? p->streams : 1u);
     ps.repack_sticky = (samples_per_stream <= c->sticky_samples && c->compact_below > 0.0) ? 1u : 0u;
+    const bool mapped = c->readback == 0u; // queue sizes reach the host by the kernels' own stores (fold_traced) instead of a copy per launch
+    ps.host_ring = mapped ? c->d_ring : nullptr; ps.ring_slots = kLag;
     const bool repack_always = ps.repack_sticky && samples_per_stream <= 2u; // nothing (or next to nothing) regenerates: every launch leaves holes
 
     FrameParams fp{};
@@ -663,9 +679,13 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     // 1 spp 0.567 / 0.537 / 0.529, 8 spp 2.79 / 2.73 / 2.70, glass 8 spp 1.57 / 1.52 / 1.48), long ones not (64 spp 17.73 / 17.68 /
     // 17.73; a rank's 1/8 2.63 / 2.59 / 2.61), and the lane-packing kernel's short tail launches want the host further ahead (soup
     // 72.3 / 72.4 / 73.1). At least 2: the launch after the last one that had paths clears that one's counter line.
-    const uint32_t lag = c->lag ? c->lag : samples_per_stream <= 2u ? 2u : 3u;
+    // With the sizes stored by the kernels themselves (pt_tuning.readback = 0) iteration j's line is written by launch j + 1, so the
+    // same run-ahead of the GPU takes one more iteration of lag than with a copy behind every launch.
+    const uint32_t lag = c->lag ? c->lag : (samples_per_stream <= 2u ? 2u : 3u) + (mapped ? 1u : 0u);
     size_t nev = 0;
     uint32_t iters_max = 0;
+    // path vertices per launch of the one-ray-per-lane kernel: 3/4 max_depth - 2 (saturating), clamped to [4, 12]
+    const uint32_t v34 = p->max_depth * 3u / 4u, default_bounces = std::min(12u, std::max(4u, v34 > 2u ? v34 - 2u : 0u));
     // 0 = probing inside this frame, else the ExtendKernel every iteration uses
     uint32_t ext_choice = forced_choice ? forced_choice : s->ext_choice ? s->ext_choice : will_probe ? 0u : frame_kernel;
     bool mixed = false; // this frame ran probe iterations on both kernels: its overall rate says nothing about either
@@ -697,7 +717,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
             const bool fused = !split_kernels;
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u], L.stream));
             HIP_TRY(c, launch_extend(L.stream, sc, pg, fp, it, L.bound, count, kernel, packed_chunk, fused ? shade_mode : -1, compact,
-                                     c->bounces ? c->bounces : use_packed ? (probing ? 8u : 64u) : std::min(12u, std::max(4u, p->max_depth * 3u / 4u - 2u))));
+                                     c->bounces ? c->bounces : use_packed ? (probing ? 8u : 64u) : default_bounces));
                                      // lane-packing: a lane pulls a new entry whenever its budget ends, so a long budget costs nothing and
                                      // saves launches (ms per frame with 8 / 16 / 32 / 64 vertices, tools/exp_packed.py: 1M soup 72.2 / 71.5 /
                                      // 70.5 / 67.4, at 256 spp 277.6 / 271.8 / 268.3 / 266.1, 5k soup 7.99 / 7.43 / 7.35 / 7.39); the probe
@@ -710,27 +730,31 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
             }
             if (probing) HIP_TRY(c, hipEventRecord(c->ev_probe[(L.iters - 2u) * 2u + 1u], L.stream)); // the whole iteration, either way
             if (profile) HIP_TRY(c, hipEventRecord(e2, L.stream));
-            const uint32_t ring = L.iters % lag;
-            uint32_t *h_ring = c->h_counts + ((size_t)g * kLag + ring) * kRingWords;
-            HIP_TRY(c, hipMemcpyAsync(h_ring, c->counters.p + cnt_ext_index((it + 1u) % 3u, L.base), sizeof(uint32_t) * per_group * kCounterStride,
-                                      hipMemcpyDeviceToHost, L.stream));
+            const uint32_t ring = L.iters % kLag;
+            if (!mapped) {
+                uint32_t *h_ring = c->h_counts + ((size_t)g * kLag + ring) * kRingWords;
+                HIP_TRY(c, hipMemcpyAsync(h_ring, c->counters.p + cnt_ext_index((it + 1u) % 3u, L.base), sizeof(uint32_t) * per_group * kCounterStride,
+                                          hipMemcpyDeviceToHost, L.stream));
+            }
             HIP_TRY(c, hipEventRecord(c->ev_lag[g][ring], L.stream));
             ++L.iters;
             iters_max = std::max(iters_max, L.iters);
             if (L.iters >= lag) {
-                const uint32_t old = (L.iters - lag) % lag; // iteration iters-lag: its survivors bound every later queue
-                HIP_TRY(c, hipEventSynchronize(c->ev_lag[g][old]));
-                const uint32_t *h_old = c->h_counts + ((size_t)g * kLag + old) * kRingWords;
+                const uint32_t old_iter = L.iters - lag; // iteration old_iter traced `traced` rays and left `total` paths alive: its survivors bound every later queue
+                // mapped: launch old_iter + 1 stored old_iter's lines (fold_traced); it is at most the launch just enqueued since lag >= 2
+                HIP_TRY(c, hipEventSynchronize(c->ev_lag[g][(mapped ? old_iter + 1u : old_iter) % kLag]));
+                const volatile uint32_t *h_old = mapped ? (const volatile uint32_t *)(c->h_ring + (size_t)(old_iter % kLag) * kShards + L.base)
+                                               : c->h_counts + ((size_t)g * kLag + old_iter % kLag) * kRingWords;
+                const uint32_t line = mapped ? 4u : kCounterStride;
                 uint32_t mx = 0;
                 // a shard's line: word 0 = queue length (holes included), word 1 = alive entries, words 2-3 = rays the iteration traced
                 uint64_t total = 0, traced = 0;
                 for (uint32_t sh = 0; sh < per_group; ++sh) {
-                    mx = std::max(mx, h_old[sh * kCounterStride]);
-                    total += h_old[sh * kCounterStride + 1];
-                    traced += (uint64_t)h_old[sh * kCounterStride + 2] | ((uint64_t)h_old[sh * kCounterStride + 3] << 32);
+                    mx = std::max(mx, (uint32_t)h_old[sh * line]);
+                    total += h_old[sh * line + 1];
+                    traced += (uint64_t)h_old[sh * line + 2] | ((uint64_t)h_old[sh * line + 3] << 32);
                 }
                 L.bound = mx;
-                const uint32_t old_iter = L.iters - lag; // iteration old_iter traced `traced` rays and left `total` paths alive
                 if (trace) {
                     trace_alive.resize(std::max<size_t>(trace_alive.size(), old_iter + 1), 0); trace_rays.resize(trace_alive.size(), 0);
                     trace_alive[old_iter] += total; trace_rays[old_iter] += traced;
@@ -791,7 +815,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     if (undecided && s->ext_choice == 0u && !mixed && !cold_frame && out.rays >= (1u << 20) && out.gpu_ms > 0.0) { // a whole frame on one kernel: remember its rate
         (frame_kernel == (uint32_t)EXT_PACKED ? s->rate_packed : s->rate_simple) = (double)out.rays / out.gpu_ms;
         if (s->rate_simple > 0.0 && s->rate_packed > 0.0) s->ext_choice = s->rate_packed > 1.10 * s->rate_simple ? (uint32_t)EXT_PACKED : (uint32_t)EXT_SIMPLE;
-    }
+    } else if (undecided && s->ext_choice == 0u && !cold_frame && ++s->probe_misses >= 3u) s->ext_choice = (uint32_t)EXT_SIMPLE; // frames too small to time
     out.reserved[0] = ext_choice ? ext_choice : (uint32_t)EXT_SIMPLE; // extend kernel in use at frame end (ExtendKernel)
     out.reserved[1] = hc[kCntCompactions]; // (shard, iteration) pairs that re-packed their queue (the others carried it over in place)
     {   // paths = owned in-image pixels x spp

@@ -250,6 +250,86 @@ void emit_blob(const std::vector<Tmp> &tn, int32_t root, const std::vector<uint3
     out.stack_need = need[0];
 }
 
+// Memory order of the node array (and optionally of the triangle array): pure renaming — refs change, the tree, the boxes and with
+// them every picture and visit counter do not (docs/SPEC.md §4.1: the order of nodes and triangles is not part of the contract).
+// Why it matters: beyond L2 the memory system moves 128-byte lines, a BVH4Q node is 64 bytes, so every node shares its line with
+// one neighbour; which neighbour decides how many of a ray's node fetches are new lines (layout experiments).
+//   order 0 : breadth-first as emitted (the children of a node are consecutive: a line holds two siblings)
+//   order 1 : depth-first pre-order (a line holds a node and its first inner child, or two nodes of neighbouring subtrees)
+//   order 2 : parent + largest child pairs, pairs in breadth-first order: a 128-byte line holds a node and the inner child of
+//             largest surface area (the one a ray that visits the node most probably visits too); nodes without inner children
+//             pair up among themselves in queue order
+//   order 3 : the same pairs in depth-first order (pairs of one subtree contiguous: van-Emde-Boas-like blocks of two)
+//   +16     : triangles re-emitted in the order the new node array references them
+void reorder_blob(BvhBlob &b, uint32_t mode)
+{
+    const uint32_t W = b.width, n = b.n_nodes, order = mode & 15u;
+    if (n < 2 || (order == 0 && !(mode & 16u))) return;
+    std::vector<uint32_t> ord; // new position -> old index
+    ord.reserve(n);
+    auto slot = [&](uint32_t i, uint32_t c) -> const BvhSlot & { return b.slots[(size_t)i * W + c]; };
+    if (order == 0) { for (uint32_t i = 0; i < n; ++i) ord.push_back(i); }
+    else if (order == 1) {
+        std::vector<uint32_t> st{ 0u };
+        while (!st.empty()) {
+            const uint32_t x = st.back(); st.pop_back();
+            ord.push_back(x);
+            for (int c = (int)W - 1; c >= 0; --c) { const int32_t r = slot(x, (uint32_t)c).ref; if (r >= 0 && r != kEmpty) st.push_back((uint32_t)r); }
+        }
+    } else {
+        std::vector<uint32_t> heads{ 0u }; // FIFO (order 2: read index) or LIFO (order 3)
+        size_t rd = 0;
+        int64_t pending = -1;
+        while (order == 2 ? rd < heads.size() : !heads.empty()) {
+            uint32_t x;
+            if (order == 2) x = heads[rd++]; else { x = heads.back(); heads.pop_back(); }
+            int best = -1; float ba = -1.f;
+            for (uint32_t c = 0; c < W; ++c) {
+                const BvhSlot &k = slot(x, c);
+                if (k.ref < 0 || k.ref == kEmpty) continue;
+                Box bx; for (int a = 0; a < 3; ++a) { bx.lo[a] = k.lo[a]; bx.hi[a] = k.hi[a]; }
+                const float ar = bx.area();
+                if (ar > ba) { ba = ar; best = (int)c; }
+            }
+            if (best < 0) { // no inner child: shares a line with the next node of its kind
+                if (pending >= 0) { ord.push_back((uint32_t)pending); ord.push_back(x); pending = -1; } else pending = x;
+                continue;
+            }
+            const uint32_t y = (uint32_t)slot(x, (uint32_t)best).ref;
+            ord.push_back(x); ord.push_back(y);
+            std::vector<uint32_t> next;
+            for (uint32_t c = 0; c < W; ++c) { const int32_t r = slot(x, c).ref; if (r >= 0 && r != kEmpty && (int)c != best) next.push_back((uint32_t)r); }
+            for (uint32_t c = 0; c < W; ++c) { const int32_t r = slot(y, c).ref; if (r >= 0 && r != kEmpty) next.push_back((uint32_t)r); }
+            if (order == 2) heads.insert(heads.end(), next.begin(), next.end());
+            else heads.insert(heads.end(), next.rbegin(), next.rend());
+        }
+        if (pending >= 0) ord.push_back((uint32_t)pending);
+    }
+    if (ord.size() != n) return; // (cannot happen for a tree) leave the blob as it is
+    std::vector<uint32_t> pos(n);
+    for (uint32_t i = 0; i < n; ++i) pos[ord[i]] = i;
+    std::vector<BvhSlot> ns((size_t)n * W);
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t c = 0; c < W; ++c) {
+            BvhSlot k = slot(ord[i], c);
+            if (k.ref >= 0 && k.ref != kEmpty) k.ref = (int32_t)pos[(uint32_t)k.ref];
+            ns[(size_t)i * W + c] = k;
+        }
+    b.slots.swap(ns);
+    if (mode & 16u) {
+        std::vector<BvhTri> nt;
+        nt.reserve(b.tris.size());
+        for (size_t i = 0; i < b.slots.size(); ++i) {
+            BvhSlot &k = b.slots[i];
+            if (k.ref >= 0) continue; // inner node or kEmpty (0x7fffffff)
+            const uint32_t enc = (uint32_t)~k.ref, first = enc >> 3, cnt = (enc & 7u) + 1u, nf = (uint32_t)nt.size();
+            for (uint32_t j = 0; j < cnt; ++j) nt.push_back(b.tris[first + j]);
+            k.ref = (int32_t)~((nf << 3) | (cnt - 1u));
+        }
+        b.tris.swap(nt);
+    }
+}
+
 } // namespace
 
 void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out)
@@ -275,6 +355,7 @@ void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint3
     Builder B(prims, idx);
     const int32_t root = build_parallel(B, n_tris);
     emit_blob(B.nodes, root, idx, verts9, mats, n_tris, width, out);
+    if (const char *e = getenv("PTRT_NODE_ORDER")) reorder_blob(out, (uint32_t)atoi(e)); // developer aid: layout experiments (tools/exp_order.py)
     out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h> // types and prototypes only; the functions are resolved at run time
 #include <dlfcn.h>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -32,14 +33,19 @@ struct Rccl {
     decltype(&ncclGather) Gather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string error;
+    bool loaded = false; // set only once all six symbols are resolved: a half-loaded library is never called
+    std::mutex mu;       // contexts (and their comms) may be created from several host threads
     bool load()
     {
-        if (handle) return true;
-        for (const char *name : { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" }) {
-            handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (handle) break;
-        }
+        std::lock_guard<std::mutex> lock(mu);
+        if (loaded) return true;
+        if (!handle)
+            for (const char *name : { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" }) {
+                handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (handle) break;
+            }
         if (!handle) { error = std::string("cannot load librccl.so.1: ") + dlerror(); return false; }
+        error.clear();
         auto sym = [&](const char *n) { void *p = dlsym(handle, n); if (!p) error = std::string("librccl lacks ") + n; return p; };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
@@ -47,7 +53,8 @@ struct Rccl {
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         Gather = (decltype(Gather))sym("ncclGather");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Gather && GetErrorString;
+        loaded = CommInitAll && CommDestroy && GroupStart && GroupEnd && Gather && GetErrorString;
+        return loaded;
     }
 };
 Rccl g_rccl;
@@ -56,6 +63,7 @@ Rccl g_rccl;
 
 struct pt_comm {
     std::vector<pt_context *> ctx; // per rank
+    std::vector<int> dev;          // per rank: the context's device (pt_comm_destroy does not touch the contexts)
     uint32_t root = 0;
     bool shared = false;           // every rank on one context (virtual ranks)
     bool use_rccl = false;
@@ -120,6 +128,7 @@ pt_status pt_comm_create(pt_context *const *ctxs, uint32_t n_ranks, uint32_t roo
     pt_comm *c = new (std::nothrow) pt_comm();
     if (!c) return cfail(nullptr, PT_ERR_OUT_OF_MEMORY, "host allocation failed");
     c->ctx.assign(ctxs, ctxs + n_ranks);
+    for (uint32_t i = 0; i < n_ranks; ++i) c->dev.push_back(context_device(ctxs[i]));
     c->root = root;
     c->shared = n_ranks > 1 && all_same;
     c->staged.assign(n_ranks, 0);
@@ -139,9 +148,10 @@ pt_status pt_comm_create(pt_context *const *ctxs, uint32_t n_ranks, uint32_t roo
 void pt_comm_destroy(pt_comm *c)
 {
     if (!c) return;
-    for (pt_context *x : c->ctx) { (void)hipSetDevice(context_device(x)); (void)hipStreamSynchronize(context_stream(x)); }
-    for (ncclComm_t m : c->comms) if (m) (void)g_rccl.CommDestroy(m);
-    if (c->gathered) { (void)hipSetDevice(context_device(c->ctx[c->root])); (void)hipFree(c->gathered); }
+    // Every pt_comm call returns with nothing of its own in flight (pt_comm_assemble waits for every rank's stream), so the
+    // contexts are not needed here and may already be gone: the order of pt_comm_destroy and pt_context_destroy is free.
+    for (size_t i = 0; i < c->comms.size(); ++i) if (c->comms[i]) { (void)hipSetDevice(c->dev[i]); (void)g_rccl.CommDestroy(c->comms[i]); }
+    if (c->gathered) { (void)hipSetDevice(c->dev[c->root]); (void)hipFree(c->gathered); }
     delete c;
 }
 
@@ -194,13 +204,24 @@ pt_status pt_comm_assemble(pt_comm *c, const pt_render_params *p)
         }
         if (c->use_rccl) {
             // one collective per frame; every rank's call sits on its own context's stream (after its kernels)
+            // Whatever fails between GroupStart and GroupEnd, the group is closed and the ranks already posted are drained before
+            // the error goes back: no open RCCL group and no collective in flight survive the call.
             C_NCCL(c, g_rccl.GroupStart());
-            for (uint32_t i = 0; i < n; ++i) {
-                C_HIP(c, hipSetDevice(context_device(c->ctx[i])));
+            pt_status posted = PT_OK;
+            uint32_t n_posted = 0;
+            for (uint32_t i = 0; i < n && posted == PT_OK; ++i) {
+                const hipError_t he = hipSetDevice(context_device(c->ctx[i]));
+                if (he != hipSuccess) { posted = cfail(c, PT_ERR_HIP, "hipSetDevice (rank %u) failed: %s", i, hipGetErrorString(he)); break; }
                 const ncclResult_t r = g_rccl.Gather(tiles[i], c->gathered, per_rank, ncclFloat, (int)c->root, c->comms[i], context_stream(c->ctx[i]));
-                if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return cfail(c, PT_ERR_HIP, "ncclGather (rank %u) failed: %s", i, g_rccl.GetErrorString(r)); }
+                if (r != ncclSuccess) { posted = cfail(c, PT_ERR_HIP, "ncclGather (rank %u) failed: %s", i, g_rccl.GetErrorString(r)); break; }
+                ++n_posted;
             }
-            C_NCCL(c, g_rccl.GroupEnd());
+            const ncclResult_t ge = g_rccl.GroupEnd();
+            if (posted != PT_OK || ge != ncclSuccess) {
+                const std::string msg = posted != PT_OK ? c->err : std::string("ncclGroupEnd failed: ") + g_rccl.GetErrorString(ge);
+                for (uint32_t i = 0; i < n_posted; ++i) { (void)hipSetDevice(context_device(c->ctx[i])); (void)hipStreamSynchronize(context_stream(c->ctx[i])); }
+                return cfail(c, posted != PT_OK ? posted : PT_ERR_HIP, "%s", msg.c_str());
+            }
         } else { // a single rank without RCCL: its block is the whole gather
             C_HIP(c, hipSetDevice(context_device(root)));
             C_HIP(c, hipMemcpyAsync(c->gathered, tiles[0], per_rank * sizeof(float), hipMemcpyDeviceToDevice, context_stream(root)));
@@ -208,6 +229,9 @@ pt_status pt_comm_assemble(pt_comm *c, const pt_render_params *p)
     }
     // un-tile on the root: same stream as the root's receive, then the host waits (pt_assemble_tiles is synchronous)
     pt_status st = pt_assemble_tiles(root, &q, c->gathered, per_rank * n);
+    if (c->use_rccl) // the senders' halves of the gather: done once the root has received, waited for so that nothing outlives the call
+        for (uint32_t i = 0; i < n; ++i)
+            if (i != c->root) { (void)hipSetDevice(c->dev[i]); (void)hipStreamSynchronize(context_stream(c->ctx[i])); }
     if (st != PT_OK) return cfail(c, st, "pt_comm_assemble: %s", pt_last_error(root));
     return PT_OK;
 }

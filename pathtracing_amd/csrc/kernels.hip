@@ -474,10 +474,14 @@ PT_DEV unsigned long long *traced_counter(const PathState &ps, uint32_t c, uint3
 {
     return reinterpret_cast<unsigned long long *>(ps.counters + cnt_traced_index(c, shard));
 }
-PT_DEV void fold_traced(const PathState &ps, uint32_t shard, uint32_t it)
+// Run by the first thread of a shard in launch `it`; (n, n_alive) = the shard's line as the previous launch left it. That line also
+// goes to the host (PathState::host_ring): a plain 16-byte store to mapped pinned memory instead of a copy dispatch per launch.
+PT_DEV void fold_traced(const PathState &ps, uint32_t shard, uint32_t it, uint32_t n, uint32_t n_alive)
 {
     *traced_counter(ps, (it + 2u) % 3u, shard) = 0ull;
-    *reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard)) += *traced_counter(ps, it % 3u, shard);
+    const unsigned long long traced = *traced_counter(ps, it % 3u, shard);
+    *reinterpret_cast<unsigned long long *>(ps.counters + cnt_rays_index(shard)) += traced;
+    if (ps.host_ring && it) ps.host_ring[((it - 1u) % ps.ring_slots) * kShards + shard] = make_uint4(n, n_alive, (uint32_t)traced, (uint32_t)(traced >> 32));
 }
 
 // Queue policy, from the shard's own counters so that every workgroup of a launch decides the same and without host lag.
@@ -642,7 +646,7 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
             ps.counters[cnt_prev_alive_index(cnext, shard)] = n_alive;
             ps.counters[cnt_ext_index(czero, shard)] = 0u;         // the queue after next
             ps.counters[cnt_alive_index(czero, shard)] = 0u;
-            fold_traced(ps, shard, it);
+            fold_traced(ps, shard, it, n, n_alive);
             if (FUSE == SHADE_NONE) *traced_counter(ps, cnext, shard) = n_alive; // one ray per alive entry; the fused kernel
                                                                                  // counts what it traces, per wavefront
             if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
@@ -806,7 +810,7 @@ k_extend_packed(ExtArgs a)
         cold().ps.counters[cnt_prev_alive_index(cnext, shard)] = n_alive; // for a one-ray-per-lane launch that may follow (probe frames)
         cold().ps.counters[cnt_ext_index(czero, shard)] = 0u;
         cold().ps.counters[cnt_alive_index(czero, shard)] = 0u;
-        fold_traced(cold().ps, shard, it);
+        fold_traced(cold().ps, shard, it, n, n_alive);
         if (FUSE == SHADE_NONE) *traced_counter(cold().ps, cnext, shard) = n_alive; // one ray per alive entry
         else if (!do_compact) cold().ps.counters[cnt_ext_index(cnext, shard)] = n;  // carried in place: the length stays
         if (do_compact && n_alive) atomicAdd(&cold().ps.counters[kCntCompactions], 1u);
@@ -1027,7 +1031,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_POOL
             ps.counters[cnt_prev_alive_index(cnext, shard)] = n_alive;
             ps.counters[cnt_ext_index(czero, shard)] = 0u;
             ps.counters[cnt_alive_index(czero, shard)] = 0u;
-            fold_traced(ps, shard, it);
+            fold_traced(ps, shard, it, n, n_alive);
             if (!do_compact) ps.counters[cnt_ext_index(cnext, shard)] = n; // carried in place: the length stays
             if (do_compact && n_alive) atomicAdd(&ps.counters[kCntCompactions], 1u);
         }

@@ -108,6 +108,11 @@ struct PathState {           // SoA over slots
     float sparse_below;      // fused one-ray-per-lane kernel: a launch that starts with alive < sparse_below * length advances one
                              // vertex only (and re-packs), instead of running `bounces` vertices on mostly idle wavefronts
     uint32_t finish_below;   // fused kernel: once a shard has no more alive paths than this, a launch runs them to their end
+    // Queue sizes for the host, without a copy dispatch between two launches: the first thread of shard s in launch `it` stores the line
+    // the PREVIOUS launch left behind (queue length, alive entries, rays it traced) to host_ring[((it - 1) % ring_slots) * kShards + s]
+    // — host-mapped pinned memory; the host reads it after the event that follows launch `it`. NULL: the host copies the lines itself.
+    uint4 *host_ring;
+    uint32_t ring_slots;
 };
 
 struct FrameParams {

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported(P):
     assert declared == set(P.native.SYMBOLS), declared ^ set(P.native.SYMBOLS)
     for name in declared:
         assert hasattr(P.native.lib, name), name
-    assert P.native.lib.pt_abi_version() == 1
+    assert P.native.lib.pt_abi_version() == P.native.PTRT_ABI_VERSION == 2
 
 
 def test_struct_layouts(P):

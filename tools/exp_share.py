@@ -1,21 +1,24 @@
-"""Experiment: a rank's 1/8 share of the headline frame (strong scaling at N = 8): ms by loops, bounces per launch, finish_below."""
-import sys; sys.path.insert(0,".")
+"""Experiment: every rank's share of the headline frame (strong scaling at N = 2, 4, 8) on ONE GPU, no communication:
+ms per rank (best of 5 warm frames), max / mean / spread over ranks, and the speed-up max-rank time would allow.
+usage: python tools/exp_share.py [readback=0|1] [lag=N] [loops=N] ..."""
+import sys; sys.path.insert(0, ".")
 import pathtracing_amd as P
-N=P.native
-W,H=1920,1080
-r=P.Renderer(P.Window(W,H)); r.Init()
-r.SetScene(P.make_scene(N.PT_SCENE_CORNELL_TESS,1<<20,0x5EED0001,W,H),0)
-def t(nr,**kw):
-    r.SetTuning(**kw)
-    r.Params=P.make_params(W,H,spp=64,max_depth=8,streams=8,rank=0,nranks=nr)
+N = P.native
+W, H = 1920, 1080
+kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:])}
+r = P.Renderer(P.Window(W, H)); r.Init()
+r.SetScene(P.make_scene(N.PT_SCENE_CORNELL_TESS, 1 << 20, 0x5EED0001, W, H), 0)
+r.SetTuning(extend_kernel=1, **kw)
+def share(rank, nr):
+    r.Params = P.make_params(W, H, spp=64, max_depth=8, streams=8, rank=rank, nranks=nr)
     for _ in range(2): r.Render(0.0)
-    b=min((r.Render(0.0) for _ in range(7)),key=lambda s:s.gpu_ms)
-    return b
-for nr in (8,4,2):
-    base=t(nr,loops=0,bounces=0,finish_below=4096)
-    print(f"ranks {nr}: default {base.gpu_ms:.3f} ms iters {base.iterations}",flush=True)
-    for loops in (1,2,4):
-        for bounces in (3,4,6,8):
-            for fb in (4096,32768):
-                b=t(nr,loops=loops,bounces=bounces,finish_below=fb)
-                print(f"  loops {loops} bounces {bounces} finish_below {fb:6d}: {b.gpu_ms:.3f} ms iters {b.iterations}",flush=True)
+    return min((r.Render(0.0) for _ in range(5)), key=lambda s: s.gpu_ms)
+one = share(0, 1)
+print(f"tuning {kw}: N=1 {one.gpu_ms:.3f} ms, {one.rays} rays, {one.iterations} launches", flush=True)
+for nr in (2, 4, 8):
+    st = [share(k, nr) for k in range(nr)]
+    ms = [s.gpu_ms for s in st]
+    print(f"N={nr}: max {max(ms):.3f} mean {sum(ms)/nr:.3f} min {min(ms):.3f} ms  max/mean {max(ms)/(sum(ms)/nr):.3f}  rays max/mean "
+          f"{max(s.rays for s in st)/(sum(s.rays for s in st)/nr):.3f}  launches {st[0].iterations}  speed-up before the gather {one.gpu_ms/max(ms):.2f}x  "
+          f"per rank: {' '.join(f'{m:.3f}' for m in ms)}", flush=True)
+r.Dispose()
