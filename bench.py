@@ -10,26 +10,28 @@ With N ranks the frame's 64x64 tiles are dealt round-robin to the ranks (docs/SP
 scene, and the only data-path collective is ONE gather of per-rank tile radiance to rank 0 per frame (RCCL over xGMI).
 Total work per frame is fixed => "scaling": "strong". value = rays traced by all ranks / wall time (max over ranks).
 
-Extra objects on the JSON line (rank 0, N = 1 only; all measured outside the timed region):
-  roofline     : the dominant kernel (the fused extend kernel: traversal + intersection + shading) against THREE ceilings, each a
-                 fraction <= 1 of something that can bind; `bound`/`frac`/`achieved`/`peak` repeat the highest one:
-                   valu_issue   wave-level VALU instructions per launch (rocprofv3 SQ_INSTS_VALU, committed pass of this very
-                                workload: profiles/pmc_latest.json) / live mean launch duration (HIP events on the library's
-                                stream), against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; plus the fraction of
-                                lanes active per VALU instruction (SQ_THREAD_CYCLES_VALU / 64 / SQ_INSTS_VALU)
-                   gather       node + triangle records fetched per second against tools/ubench/gather_tree run live at the
-                                scene's footprint: the same dependent 64-byte gathers with no arithmetic at all
-                   hbm_measured rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch / live launch duration / 8 TB/s
-                 Launch durations are taken on a frame with PT_FLAG_PROFILE_KERNELS: full-grid launches, one after the other (the
-                 timed frames run two half-grid shard-group loops on two streams whose launches overlap — roofline.timed_region).
-                 hbm_algorithmic (SURVEY §8d's bytes-per-ray formula) is reported next to them but is NOT a roofline here: those
-                 bytes are served by L1/L2/Infinity Cache, so the figure can exceed the HBM peak (it did in round 1).
+Extra objects on the JSON line (rank 0; all measured outside the timed region):
+  roofline     : (N = 1) the dominant kernel — the fused extend kernel: traversal + intersection + shading — against the HBM roof
+                 north_star names. `bound` "hbm"; `achieved` = HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 on gfx950 +
+                 WRITE_SIZE: the committed counter passes of this very workload, profiles/pmc/<name>.json, accepted only while
+                 sha256(kernels.hip + pt_device.h + ptrt_internal.h) is the one they were taken on — `counters` says) / the live mean
+                 launch duration (HIP events on the library's stream, PT_FLAG_PROFILE_KERNELS: full-grid launches one at a time);
+                 `peak` 8 TB/s, and the fraction of the 6.29 TB/s achievable peak beside it; `traffic` = those bytes per launch.
+                 Beside it: hbm_algorithmic (SURVEY 8d's bytes per ray x rays per launch / launch duration — cache-served, may
+                 exceed the peak: no ceiling), valu_issue (SQ_INSTS_VALU per launch / duration against 1024 SIMDs x 2.4 GHz / 2
+                 cycles per wave64 instruction; lanes active per VALU instruction; wave-time split), cache (L1 / L2 hit rates, L2
+                 line fills per ray), gather_model (records per second against tools/ubench/gather_tree run live — a MODEL of this
+                 repo's own making, a soft ceiling that real rays can beat, not a hardware limit).
   parity       : rmse_vs_oracle and pixels_differing of the benchmarked frame against the scalar C oracle at the same spp and seed.
   cpu_baseline : the scalar C oracle ("port"; the reference has no CPU path and cannot be built here) timed on this host's
                  cores on the same workload, all threads and one thread.
-  configs      : BASELINE configs C2, C3, C4 (and C5's frame on this one GPU) timed the same way, a few frames each.
+  configs      : BASELINE configs C2, C3, C4, C5's frame on this one GPU, and the reference's own kernel (Test.hlsl:1-40), each
+                 timed the same way with the same roofline object for its dominant kernel.
+  ranks        : (N > 1) every rank's wall time, rays, kernel time per frame (max / mean), and the HBM-side bandwidth its share
+                 stands for (bytes per ray of the single-GPU counter pass x its rays / its kernel time) against both peaks.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -40,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+HBM_ACHIEVABLE_GBS = 6290.0    # measured achievable, same guide ("8 TB/s peak (spec); ~6.3 TB/s achievable"; SURVEY 8d quotes 6.29)
 VALU_PEAK_GINST = 1024 * 2.4 / 2.0  # G wave64 VALU instructions per second: 256 CUs x 4 SIMD-32, 2 cycles per instruction, 2.4 GHz max clock
 KERNEL_NAMES = {0: "unprobed", 1: "k_extend", 2: "k_extend_packed", 3: "k_extend_pool"}
 
@@ -153,10 +156,11 @@ def main():
         pipe.finish()
     barrier()
     t0 = time.perf_counter()
-    rays = 0
+    rays, gpu_ms_sum = 0, 0.0
     for _ in range(args.steps):
         st = step()
         rays += st.rays
+        gpu_ms_sum += st.gpu_ms
     if pipe:
         pipe.finish()  # inside the timed region: the last frame's gather and un-tiling
     barrier()
@@ -164,12 +168,14 @@ def main():
     kernel_choice = KERNEL_NAMES[int(st.reserved[0])]
     frame = r.ReadFramebuffer() if rank == 0 else None  # the benchmarked frame (every timed frame is this frame)
 
+    per_rank = None
     if world > 1:
         dev = "cpu" if args.rehearse_gloo else "cuda"
-        tot = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=dev)
-        tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tot.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, rays_all = float(tmax[0]), float(tsum[1])
+        tot = torch.tensor([elapsed, float(rays), gpu_ms_sum], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(tot) for _ in range(world)]
+        dist.all_gather(allr, tot)  # every rank's wall time, rays and kernel time (timing report, outside the timed region)
+        per_rank = [[float(v) for v in t] for t in allr]
+        elapsed, rays_all = max(t[0] for t in per_rank), sum(t[1] for t in per_rank)
     else:
         rays_all = float(rays)
 
@@ -195,10 +201,29 @@ def main():
                        "extend_kernel": kernel_choice, "parallelism": f"tiles{world}" + ("-gloo-rehearsal" if args.rehearse_gloo else "-exchange-forced" if args.force_exchange else "")},
         }
 
+    if rank == 0 and per_rank:
+        # what every GPU did: its share of the frame (kernel time per frame from HIP events inside pt_render), and the HBM-side bandwidth that
+        # share stands for — bytes per ray of the committed single-GPU counter pass of this workload x the rank's rays / its kernel time
+        gms = [t[2] / args.steps for t in per_rank]
+        ranks = {"wall_s": [round(t[0], 4) for t in per_rank], "rays_per_frame": [int(t[1] / args.steps) for t in per_rank],
+                 "gpu_ms_per_frame": [round(g, 3) for g in gms], "gpu_ms_max_over_mean": round(max(gms) / (sum(gms) / len(gms)), 4)}
+        pmc, status = load_pmc("tess", [args.scene, args.tris, W, H, args.spp, args.max_depth, args.streams, int(info.width)], kernel_choice)
+        if pmc and args.scene == "cornell_tess":
+            bpr = pmc["hbm_bytes_per_launch"] / pmc["rays_per_launch"]
+            gbs = [bpr * t[1] / (t[2] * 1e-3) / 1e9 for t in per_rank]
+            ranks["hbm_measured_per_gpu"] = {"achieved_gbs": [round(g, 1) for g in gbs], "frac_of_8000": [round(g / HBM_PEAK_GBS, 4) for g in gbs],
+                                             "frac_of_6290": [round(g / HBM_ACHIEVABLE_GBS, 4) for g in gbs], "bytes_per_ray": round(bpr, 1),
+                                             "note": "bytes per ray from the single-GPU rocprofv3 pass of this workload (profiles/pmc/tess.json: " + status + ")"}
+        else:
+            ranks["hbm_measured_per_gpu"] = None
+            ranks["note"] = status
+        out["ranks"] = ranks
     single = rank == 0 and world == 1
     # ---- roofline of the dominant kernel (untimed extra frames)
     if single and not args.no_roofline:
-        out["roofline"] = roofline(P, r, mk, args, info, kernel_choice, W, H)
+        pmc_name = {"cornell_tess": "tess", "cornell": "cornell", "cornell_glass": "glass", "soup": "soup"}[args.scene] + ("4k" if (W, H) == (3840, 2160) else "")
+        key = [args.scene, args.tris if args.scene in ("cornell_tess", "soup") else 0, W, H, args.spp, args.max_depth, args.streams, int(info.width)]
+        out["roofline"] = kernel_roofline(P, r, mk, info, kernel_choice, pmc_name, key)
         out["roofline"]["timed_region"] = {"loops": int(r.GetTuning().loops) or 2, "frame_ms": out["ms_per_step"],
                                            "note": "the timed frames run the library default: two independent shard-group loops on two streams, "
                                                    "half-grid launches that overlap; launch durations and ceilings above are from frames whose "
@@ -232,7 +257,7 @@ def main():
                                                              f"{args.cpu_seconds:.0f} s): frame not compared here; tests/test_gpu_parity.py does"}
     # ---- the other BASELINE configs on this GPU
     if single and not args.no_configs:
-        out["configs"] = other_configs(P, r, W, H)
+        out["configs"] = other_configs(P, r, W, H, want_roofline=not args.no_roofline)
     if rank == 0:
         print(json.dumps(out), flush=True)
     r.Dispose()
@@ -241,102 +266,177 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(P, r, mk, args, info, kernel_choice, W, H):
+def source_hash():
+    """sha256 of the kernel sources a counter profile belongs to (tools/profile_config.sh computes the same on the GPU box)."""
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "pt_device.h", "ptrt_internal.h"):
+        h.update(open(os.path.join(ROOT, "pathtracing_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def load_pmc(name, key, kernel_choice):
+    """The committed rocprofv3 counter passes of a configuration (profiles/pmc/<name>.json), or (None, why). Accepted only if the
+    workload matches (samples per pixel may differ: every figure is used per ray), the kernel is the one that ran, and the kernel
+    sources are the ones the counters were taken on."""
+    path = os.path.join(ROOT, "profiles", "pmc", name + ".json")
+    try:
+        j = json.load(open(path))
+    except (OSError, ValueError):
+        return None, f"no counter profile {os.path.relpath(path, ROOT)}"
+    k, want = j.get("workload_key") or [], list(key)
+    if len(k) != 8 or k[:4] + k[5:] != want[:4] + want[5:]:
+        return None, f"counter profile is of another workload ({k} vs {want})"
+    if not (j.get("kernel", "") == kernel_choice or j.get("kernel", "").startswith(kernel_choice + "<")):
+        return None, f"counter profile is of {j.get('kernel')}, this run used {kernel_choice}"
+    if j.get("source_sha256") != source_hash():
+        return None, "counter profile is stale: kernels.hip / pt_device.h / ptrt_internal.h changed since it was taken (counter legs dropped)"
+    return j, "fresh: workload, kernel and source hash match"
+
+
+def kernel_roofline(P, r, mk, info, kernel_choice, pmc_name, key, gather_exe=True):
+    """Roofline of the dominant kernel of the scene `r` holds. mk(spp=, flags=) builds this configuration's render params."""
     N = P.native
     r.Params = mk(flags=N.PT_FLAG_PROFILE_KERNELS)
     r.Render(0.0)
     sp = r.Render(0.0)
-    r.Params = mk(spp=max(1, min(args.spp, 8)), flags=N.PT_FLAG_COUNT_VISITS)
+    r.Params = mk(spp=max(1, min(key[4], 8)), flags=N.PT_FLAG_COUNT_VISITS)
     sc = r.Render(0.0)
     n_nodes_ray, n_tris_ray, n_sph_ray = sc.node_visits / sc.rays, sc.tri_tests / sc.rays, sc.sphere_tests / sc.rays
-    node_bytes = {2: 64.0, 4: 128.0, 68: 64.0, 72: 96.0}[info.width]
+    node_bytes = {2: 64.0, 4: 128.0, 68: 64.0, 72: 96.0, 73: 96.0}[info.width]
     launches = sp.extend_launches
     launch_s = sp.extend_ms * 1e-3 / launches
     rays_per_launch = sp.rays / launches
-    # -- gather: node + triangle records per second vs the same gathers with no arithmetic (tools/ubench/gather_tree, live)
+    # -- HBM, measured: rocprofv3 FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per launch, from the committed counter passes of this workload
+    pmc, status = load_pmc(pmc_name, key, kernel_choice)
+    valu = hbm_measured = traffic = cache = None
+    if pmc:
+        c = pmc["per_launch"]
+        scale = rays_per_launch / pmc["rays_per_launch"]  # per-ray figures: identical workload => 1.0; guards against another launch count / spp
+        hb = pmc["hbm_bytes_per_launch"] * scale
+        gbs = hb / launch_s / 1e9
+        hbm_measured = {"achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4),
+                        "bytes_per_ray": round(pmc["hbm_bytes_per_launch"] / pmc["rays_per_launch"], 1)}
+        traffic = {"bytes_per_launch": round(hb), "source": pmc["source"]}
+        if "SQ_INSTS_VALU" in c:
+            insts = c["SQ_INSTS_VALU"] * scale
+            valu = {"achieved": round(insts / launch_s / 1e9, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s",
+                    "frac": round(insts / launch_s / 1e9 / VALU_PEAK_GINST, 4),
+                    "active_lane_frac": round(c["SQ_THREAD_CYCLES_VALU"] / 64.0 / c["SQ_INSTS_VALU"], 4),
+                    "valu_insts_per_ray_slot": round(c["SQ_INSTS_VALU"] * 64.0 / pmc["rays_per_launch"], 1),
+                    "wave_time": {k: round(c[k] / c["SQ_WAVE_CYCLES"], 3) for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
+                    "effective_clock_ghz_under_profiler": pmc.get("effective_clock_ghz")}
+        if "TCC_MISS_sum" in c and "TCP_TCC_READ_REQ_sum" in c:
+            cache = {"l1_hit": round(1 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"], 3),
+                     "l2_hit": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3),
+                     "l2_miss_lines_per_ray": round(c["TCC_MISS_sum"] / pmc["rays_per_launch"], 3),
+                     "mean_l1_miss_latency_cycles": round(c["TCP_TCC_READ_REQ_LATENCY_sum"] / max(c["TCP_TCC_READ_REQ_sum"], 1))}
+    # -- SURVEY §8d's algorithmic bytes per ray x rays per launch / launch duration (the contract's `achieved`): cache-served, so it
+    #    can exceed the HBM peak and is reported beside the measured figure, not instead of it
+    fused = sp.shade_ms < 0.05 * sp.extend_ms
+    b_trav = node_bytes * n_nodes_ray + 48.0 * n_tris_ray + 16.0 * n_sph_ray
+    b_ray = b_trav + (112.0 * int(sp.reserved[2]) / sp.rays + 32.0 * sp.paths / sp.rays if fused else 44.0)
+    b_8d = b_trav + 172.0 + 32.0 * sp.paths / sp.rays
+    alg_gbs = b_8d * rays_per_launch / launch_s / 1e9
+    algorithmic = {"bytes_per_ray_survey_8d_q172": round(b_8d, 1), "bytes_per_ray_as_built": round(b_ray, 1), "traversal_bytes_per_ray": round(b_trav, 1),
+                   "achieved": round(alg_gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+                   "measured_over_algorithmic": round(hbm_measured["bytes_per_ray"] / b_8d, 3) if hbm_measured else None,
+                   "note": "served by L1 / L2 / Infinity Cache (scene resident on-die): may exceed the HBM peak, so it is no ceiling; "
+                           "measured traffic well below it = no wasted re-reads"}
+    # -- gather MODEL (soft ceiling of this repo's own making, not a hardware limit): node + triangle records per second against
+    #    tools/ubench/gather_tree run live at the scene's footprint — the same dependent 64-byte gathers with no arithmetic at all
     records_per_s = (n_nodes_ray + n_tris_ray) * rays_per_launch / launch_s
-    gather = {"achieved": round(records_per_s / 1e9, 2), "peak": None, "unit": "G records/s", "frac": None,
-              "records_per_ray": round(n_nodes_ray + n_tris_ray, 2)}
+    gather = {"kind": "model, not a hardware ceiling: one uniformly random node per level; real rays revisit siblings and share lines across lanes, "
+                      "so a frac near or above 1 means the model is beaten, not the hardware",
+              "achieved": round(records_per_s / 1e9, 2), "peak": None, "unit": "G records/s", "frac": None, "records_per_ray": round(n_nodes_ray + n_tris_ray, 2)}
     exe = os.path.join(ROOT, "tools", "ubench", "gather_tree")
-    if os.path.exists(exe):
-        # a ray cannot descend further than the tree is deep: visits beyond that are returns to (warm) siblings, not new cold levels
+    if gather_exe and os.path.exists(exe) and info.n_tris >= 1000:
         levels, tris = max(1, min(round(n_nodes_ray), int(info.max_depth) - 1)), max(0, round(n_tris_ray))
         try:
             o = subprocess.run([exe, str(levels), f"{info.node_bytes / 1e6:.1f}", str(tris), f"{info.n_tris * 64 / 1e6:.1f}"], capture_output=True,
                                text=True, timeout=60).stdout.strip().splitlines()[-1]
             g = json.loads(o)
             gather.update(peak=g["g_records_per_s"], frac=round(records_per_s / 1e9 / g["g_records_per_s"], 4),
-                          model=f"dependent 64-B gathers, no arithmetic: {levels} levels of a breadth-first 4-ary tree in {info.node_bytes / 1e6:.1f} MB + "
-                                f"{tris} triangle record(s) from {info.n_tris * 64 / 1e6:.1f} MB per ray, 7 waves/SIMD (tools/ubench/gather_tree.hip)")
-        except Exception as e:  # the ceiling is a diagnostic: the benchmark line does not depend on it
+                          model=f"{levels} levels of a breadth-first 4-ary tree in {info.node_bytes / 1e6:.1f} MB + {tris} triangle record(s) from "
+                                f"{info.n_tris * 64 / 1e6:.1f} MB per ray, 7 waves/SIMD (tools/ubench/gather_tree.hip)")
+        except Exception as e:  # a diagnostic: the benchmark line does not depend on it
             gather["note"] = f"gather_tree failed: {e}"
-    # -- counters of the committed rocprofv3 passes (same workload, same kernel): per-ray figures are properties of the workload
-    pmc, valu, hbm_measured, traffic = None, None, None, None
-    try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        if ("per_launch" in j and j.get("workload_key") == [args.scene, args.tris, W, H, args.spp, args.max_depth, args.streams, info.width]
-                and j.get("kernel", "").startswith(kernel_choice + "<")):
-            pmc = j
-    except (OSError, ValueError):
-        pass
-    if pmc:
-        c = pmc["per_launch"]
-        scale = rays_per_launch / pmc["rays_per_launch"]  # identical workload => 1.0; guards against a changed launch count
-        insts = c["SQ_INSTS_VALU"] * scale
-        valu = {"achieved": round(insts / launch_s / 1e9, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s",
-                "frac": round(insts / launch_s / 1e9 / VALU_PEAK_GINST, 4),
-                "active_lane_frac": round(c["SQ_THREAD_CYCLES_VALU"] / 64.0 / c["SQ_INSTS_VALU"], 4),
-                "valu_insts_per_ray_slot": round(c["SQ_INSTS_VALU"] * 64.0 / pmc["rays_per_launch"], 1),
-                "wave_time": {k: round(c[k] / c["SQ_WAVE_CYCLES"], 3) for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
-                "effective_clock_ghz_under_profiler": pmc.get("effective_clock_ghz"), "source": pmc["source"]}
-        hb = pmc["hbm_bytes_per_launch"] * scale
-        hbm_measured = {"achieved": round(hb / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hb / launch_s / 1e9 / HBM_PEAK_GBS, 4)}
-        traffic = {"bytes_per_launch": round(hb), "source": pmc["source"]}
-    # -- SURVEY §8d's algorithmic bytes (not a roofline for this kernel, see the docstring)
-    fused = sp.shade_ms < 0.05 * sp.extend_ms
-    b_trav = node_bytes * n_nodes_ray + 48.0 * n_tris_ray + 16.0 * n_sph_ray
-    b_ray = b_trav + (112.0 * int(sp.reserved[2]) / sp.rays + 32.0 * sp.paths / sp.rays if fused else 44.0)
-    algorithmic = {"bytes_per_ray": round(b_ray, 1), "traversal_bytes_per_ray": round(b_trav, 1),
-                   "bytes_per_ray_survey_8d_q172": round(b_trav + 172.0 + 32.0 * sp.paths / sp.rays, 1),
-                   "gb_per_s": round(b_ray * rays_per_launch / launch_s / 1e9, 1),
-                   "note": "cache-served (L1 hit ~87 %, scene resident in L2 / Infinity Cache): may exceed the 8 TB/s HBM peak, so it is no ceiling"}
-    cands = {k: v for k, v in (("valu_issue", valu), ("gather", gather), ("hbm", hbm_measured)) if v and v.get("frac") is not None}
-    bound = max(cands, key=lambda k: cands[k]["frac"]) if cands else None
-    top = cands[bound] if bound else {"achieved": None, "peak": None, "unit": None, "frac": None}
+    elif info.n_tris < 1000:
+        gather["note"] = "tree of a few L1-resident lines: not a gather-bound configuration"
+    legs = {k: v["frac"] for k, v in (("hbm_measured", hbm_measured), ("valu_issue", valu), ("gather_model", gather)) if v and v.get("frac") is not None}
+    top = hbm_measured or algorithmic
     return {
-        "bound": bound, "kernel": f"{kernel_choice}<{info.width}{', fused shade' if fused else ''}>", "achieved": top["achieved"], "peak": top["peak"],
-        "unit": top["unit"], "frac": top["frac"], "traffic": traffic,
-        "valu_issue": valu, "gather": gather, "hbm_measured": hbm_measured, "hbm_algorithmic": algorithmic,
+        "bound": "hbm", "kernel": f"{kernel_choice}<{info.width}{', fused shade' if fused else ''}>",
+        "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"],
+        "frac_of_achievable_6290": round(top["achieved"] / HBM_ACHIEVABLE_GBS, 4),
+        "achieved_is": "measured HBM-side bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE) per launch / live mean launch duration" if hbm_measured
+                       else "ALGORITHMIC bytes (SURVEY 8d) per launch / live mean launch duration: the counter profile was not usable",
+        "traffic": traffic, "counters": status, "hbm_measured": hbm_measured, "hbm_algorithmic": algorithmic, "valu_issue": valu, "cache": cache,
+        "gather_model": gather, "highest_leg": max(legs, key=legs.get) if legs else None,
         "nodes_per_ray": round(n_nodes_ray, 2), "tris_per_ray": round(n_tris_ray, 2), "spheres_per_ray": round(n_sph_ray, 2),
         "path_states_per_ray": round(int(sp.reserved[2]) / sp.rays, 3), "launches": launches, "mean_launch_ms": round(launch_s * 1e3, 4),
         "rays_per_launch": round(rays_per_launch, 1), "extend_ms": round(sp.extend_ms, 2), "shade_ms": round(sp.shade_ms, 2),
         "frame_ms_profiled": round(sp.gpu_ms, 2),
-        "note": "no single unit saturates: the kernel is a chain of dependent 64-byte gathers (latency), with VALU issue and the gather "
-                "rate each around half to two thirds of their ceilings (DESIGN.md §5)",
     }
 
 
-def other_configs(P, r, W, H):
-    """BASELINE configs C2..C4 at their stated sizes and C5's 4K / 1024 spp frame, on this one GPU: ms per frame and Mrays/s."""
+def other_configs(P, r, W, H, want_roofline):
+    """BASELINE configs C2..C4 at their stated sizes, C5's 4K / 1024 spp frame on this one GPU and the reference's own kernel: ms per
+    frame, Mrays/s, and the roofline of each one's dominant kernel."""
     N = P.native
-    cfgs = [("C2", "cornell", N.PT_SCENE_CORNELL, 0, W, H, 64, 8, 5),
-            ("C3", "soup_1M", N.PT_SCENE_TRIANGLE_SOUP, 1 << 20, W, H, 64, 8, 5),
-            ("C4", "cornell_glass_metal", N.PT_SCENE_CORNELL_GLASS, 0, W, H, 256, 16, 5),
-            ("C5-on-1-GPU", "cornell_tess_1M_4K", N.PT_SCENE_CORNELL_TESS, 1 << 20, 3840, 2160, 1024, 8, 1)]
+    #        name   label                  pmc        scene key        kind                      detail   w  h  spp  depth frames
+    cfgs = [("C2", "cornell", "cornell", "cornell", N.PT_SCENE_CORNELL, 0, W, H, 64, 8, 5),
+            ("C3", "soup_1M", "soup", "soup", N.PT_SCENE_TRIANGLE_SOUP, 1 << 20, W, H, 64, 8, 5),
+            ("C4", "cornell_glass_metal", "glass", "cornell_glass", N.PT_SCENE_CORNELL_GLASS, 0, W, H, 256, 16, 5),
+            ("C5-on-1-GPU", "cornell_tess_1M_4K", "tess4k", "cornell_tess", N.PT_SCENE_CORNELL_TESS, 1 << 20, 3840, 2160, 1024, 8, 1)]
     res = []
-    for name, label, kind, detail, w, h, spp, depth, frames in cfgs:
+    for name, label, pmc_name, scene_key, kind, detail, w, h, spp, depth, frames in cfgs:
         r.SetScene(P.make_scene(kind, detail, 0x5EED0001, w, h), 0)
-        r.Params = P.make_params(w, h, spp=spp, max_depth=depth, streams=8)
+
+        def mk(spp=spp, flags=0, w=w, h=h, depth=depth):
+            return P.make_params(w, h, spp=spp, max_depth=depth, streams=8, flags=flags)
+        r.Params = mk()
         r.Render(0.0)  # warm-up (and the extend-kernel probe of a new scene)
+        r.Render(0.0)
         t0 = time.perf_counter()
         rays = 0
         for _ in range(frames):
             st = r.Render(0.0)
             rays += st.rays
         dt = time.perf_counter() - t0
-        res.append({"config": name, "scene": label, "width": w, "height": h, "spp": spp, "max_depth": depth, "frames": frames,
-                    "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
-                    "rays_per_frame": int(rays / frames), "extend_kernel": KERNEL_NAMES[int(st.reserved[0])], "bvh": int(r.BvhInfo().width)})
+        info = r.BvhInfo()
+        e = {"config": name, "scene": label, "width": w, "height": h, "spp": spp, "max_depth": depth, "frames": frames,
+             "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
+             "rays_per_frame": int(rays / frames), "extend_kernel": KERNEL_NAMES[int(st.reserved[0])], "bvh": int(info.width)}
+        if want_roofline:
+            kflag = {1: N.PT_FLAG_EXTEND_SIMPLE, 2: N.PT_FLAG_EXTEND_PACKED, 3: N.PT_FLAG_EXTEND_POOL}[int(st.reserved[0])]
+            spp_r = min(spp, 64)  # the profiled frame: per-ray figures do not depend on the sample count
+
+            def mkr(spp=spp_r, flags=0, mk=mk, kflag=kflag):
+                return mk(spp=spp, flags=flags | kflag)
+            key = [scene_key, detail, w, h, spp_r, depth, 8, int(info.width)]
+            e["roofline"] = kernel_roofline(P, r, mkr, info, e["extend_kernel"], pmc_name, key)
+        res.append(e)
+    # the reference's own kernel (Test.hlsl:1-40 -> k_reference_sphere): one float4 + one RGBA8 store per pixel, 20 B/pixel
+    r.Params = P.make_params(W, H, mode=N.PT_REFERENCE_SPHERE)
+    for _ in range(5):
+        r.Render(0.0)
+    ms = sorted(r.Render(0.0).gpu_ms for _ in range(50))
+    mean_ms = sum(ms) / len(ms)
+    gbs = 20.0 * W * H / (mean_ms * 1e-3) / 1e9
+    e = {"config": "reference_sphere", "scene": "Test.hlsl:1-40 (one hard-coded sphere, 1 ray per pixel, depth 0)", "width": W, "height": H,
+         "frames": len(ms), "ms_per_frame": round(mean_ms, 4), "ms_per_frame_min": round(ms[0], 4), "value": round(W * H / (mean_ms * 1e-3) / 1e6, 1),
+         "unit": "Mrays/s", "extend_kernel": "k_reference_sphere",
+         "roofline": {"bound": "hbm", "kernel": "k_reference_sphere", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_achievable_6290": round(gbs / HBM_ACHIEVABLE_GBS, 4),
+                      "achieved_is": "algorithmic bytes written (20 B/pixel: float4 + RGBA8, Test.hlsl:39) / mean kernel duration (HIP events); a 41 MB "
+                                     "frame is a ~10 us kernel: launch ramp and tail, not bandwidth, set its duration",
+                      "traffic": None}}
+    pmc, status = load_pmc("sphere", ["sphere", 0, W, H, 1, 0, 0, 0], "k_reference_sphere")
+    if pmc:
+        e["roofline"]["traffic"] = {"bytes_per_launch": pmc["hbm_bytes_per_launch"], "source": pmc["source"]}
+    e["roofline"]["counters"] = status
+    res.append(e)
     return res
 
 

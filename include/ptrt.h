@@ -79,6 +79,8 @@ enum {
     PT_BVH_WIDTH_4Q = 68,     /* 4-wide, 64-B nodes, child boxes quantised to 8 bits on a per-node power-of-two grid */
     PT_BVH_WIDTH_8Q = 72,     /* 8-wide, one 128-B cache line per node (96 B used), the same quantisation: a node visit costs the
                                  memory system one line either way, and there are fewer visits */
+    PT_BVH_WIDTH_8O = 73,     /* the 128-B node of PT_BVH_WIDTH_8Q with the children placed in slots by the octant of the node they lie in:
+                                 visited in the order slot ^ (sign bits of the ray direction), no distance sort (docs/SPEC.md §4.1) */
     PT_BVH_BUILD_LBVH = 0x100 /* OR-ed onto a layout: build the hierarchy on the GPU (Morton sort + Karras + refit) instead of the
                                  host's binned-SAH builder. Faster to build, slower to trace; the picture is identical either way. */
 };
@@ -135,11 +137,11 @@ typedef struct {
 } pt_stats;
 
 typedef struct {
-    uint32_t width;          /* the layout id the scene was committed with: PT_BVH_WIDTH_2, _4, _4Q or _8Q */
+    uint32_t width;          /* the layout id the scene was committed with: PT_BVH_WIDTH_2, _4, _4Q, _8Q or _8O */
     uint32_t n_nodes;
     uint32_t n_tris;
     uint32_t max_depth;
-    uint64_t node_bytes;     /* n_nodes * 64 (layouts 2 and 4Q) or n_nodes * 128 (layouts 4 and 8Q) */
+    uint64_t node_bytes;     /* n_nodes * 64 (layouts 2 and 4Q) or n_nodes * 128 (layouts 4, 8Q and 8O) */
     uint64_t tri_bytes;      /* n_tris * 48: the blob's triangle records as pt_scene_bvh_read copies them out (docs/SPEC.md §4.1). On the device
                                 every record is padded to one 64-byte line (+ a shading row): n_tris * 64 bytes of HBM */
     double build_ms;

@@ -189,7 +189,7 @@ static inline void test_sphere(const pto_scene *s, uint32_t j, v3 o, v3 d, hit_t
  * with box = fma((float)q, 2^(e-127), origin) per axis. */
 static uint32_t node_children(uint32_t layout, const void *nodes, uint32_t i, slot_t out[8])
 {
-    if (layout == PTO_BVH_LAYOUT_8Q) { /* 128-byte node: +16 ref i32[8] | +48 qlo_x,qlo_y,qlo_z (u8[8] each) | +72 qhi_x,qhi_y,qhi_z */
+    if (layout == PTO_BVH_LAYOUT_8Q || layout == PTO_BVH_LAYOUT_8O) { /* 128-byte node: +16 ref i32[8] | +48 qlo_x,qlo_y,qlo_z (u8[8] each) | +72 qhi_x,qhi_y,qhi_z */
         const uint8_t *nd = (const uint8_t *)nodes + (size_t)i * 128;
         float org[3], sc[3];
         memcpy(org, nd, 12);
@@ -252,7 +252,10 @@ static void closest_hit(const pto_scene *s, v3 o, v3 d, hit_t *h, pto_stats *st)
             uint32_t keys[8]; int32_t refs[8]; int nh = 0;
             /* quantised layouts (SPEC §4.1): the slab distances come straight from the bytes, t = fma(q, A, B) with
              * A = 2^e * inv (exact) and B = fma(origin, inv, noi) per axis and node */
-            const int quant = s->bvh_width == PTO_BVH_LAYOUT_4Q || s->bvh_width == PTO_BVH_LAYOUT_8Q;
+            const int quant = s->bvh_width == PTO_BVH_LAYOUT_4Q || s->bvh_width == PTO_BVH_LAYOUT_8Q || s->bvh_width == PTO_BVH_LAYOUT_8O;
+            /* layout 8O (SPEC §4.1): no distance sort; the visit order of the hit slots is ascending slot ^ octant, octant bit k = inv.k < 0 */
+            const uint32_t octant = (inv[0] < 0.0f ? 1u : 0u) | (inv[1] < 0.0f ? 2u : 0u) | (inv[2] < 0.0f ? 4u : 0u);
+            const int by_octant = s->bvh_width == PTO_BVH_LAYOUT_8O;
             const uint8_t *raw = NULL; float qa[3] = { 0, 0, 0 }, qb[3] = { 0, 0, 0 };
             if (quant) {
                 raw = (const uint8_t *)s->nodes + (size_t)ref * (N == 8 ? 128 : 64);
@@ -274,7 +277,7 @@ static void closest_hit(const pto_scene *s, v3 o, v3 d, hit_t *h, pto_stats *st)
                 }
                 float tn = max_(max_(min_(tax, tbx), min_(tay, tby)), max_(min_(taz, tbz), 0.0f));
                 float tf = min_(min_(max_(tax, tbx), max_(tay, tby)), min_(max_(taz, tbz), h->t)) * 1.0000004f;
-                if (tn <= tf) { keys[nh] = (f2bits(tn) & ~slot_mask) | c; refs[nh] = nd[c].ref; nh++; }
+                if (tn <= tf) { keys[nh] = by_octant ? (c ^ octant) : ((f2bits(tn) & ~slot_mask) | c); refs[nh] = nd[c].ref; nh++; }
             }
             /* push in descending key order */
             for (int i = 1; i < nh; ++i) {
@@ -488,7 +491,7 @@ int pto_render(const pto_scene *s, const pto_params *p, int threads, float *rgba
     for (uint32_t i = 0; i < s->n_tris; ++i) if (s->tri_mat && s->tri_mat[i] >= s->n_mats) return -3;
     for (uint32_t i = 0; i < s->n_spheres; ++i) if (s->sph_mat && s->sph_mat[i] >= s->n_mats) return -3;
     if ((s->n_tris || s->n_spheres) && s->n_mats == 0) return -3;
-    if (s->nodes && s->bvh_width != 2 && s->bvh_width != 4 && s->bvh_width != PTO_BVH_LAYOUT_4Q && s->bvh_width != PTO_BVH_LAYOUT_8Q) return -4;
+    if (s->nodes && s->bvh_width != 2 && s->bvh_width != 4 && s->bvh_width != PTO_BVH_LAYOUT_4Q && s->bvh_width != PTO_BVH_LAYOUT_8Q && s->bvh_width != PTO_BVH_LAYOUT_8O) return -4;
     pto_stats tot; memset(&tot, 0, sizeof tot);
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
@@ -624,10 +627,10 @@ void pto_free(void *p) { free(p); }
 int pto_bvh_validate(uint32_t width, uint32_t n_nodes, const void *nodes_v, const void *tris_v,
                      uint32_t n_tris, const float *tri_verts, const uint32_t *tri_mat, uint32_t *max_depth_out)
 {
-    if (width != 2 && width != 4 && width != PTO_BVH_LAYOUT_4Q && width != PTO_BVH_LAYOUT_8Q) return -1;
+    if (width != 2 && width != 4 && width != PTO_BVH_LAYOUT_4Q && width != PTO_BVH_LAYOUT_8Q && width != PTO_BVH_LAYOUT_8O) return -1;
     if (n_tris == 0) return n_nodes == 0 ? 0 : -2;
     if (n_nodes == 0 || !nodes_v || !tris_v) return -2;
-    const uint32_t W = (width == 2) ? 2u : (width == PTO_BVH_LAYOUT_8Q) ? 8u : 4u;
+    const uint32_t W = (width == 2) ? 2u : (width == PTO_BVH_LAYOUT_8Q || width == PTO_BVH_LAYOUT_8O) ? 8u : 4u;
     const tri48_t *tris = (const tri48_t *)tris_v;
     uint8_t *seen = (uint8_t *)calloc(n_tris, 1), *nseen = (uint8_t *)calloc(n_nodes, 1);
     typedef struct { int32_t ref; box_t box; uint32_t depth; } ent;

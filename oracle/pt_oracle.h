@@ -29,6 +29,7 @@ enum { PTO_LAMBERT = 0, PTO_METAL = 1, PTO_DIELECTRIC = 2 };
 #define PTO_BVH_EMPTY 0x7fffffff
 #define PTO_BVH_LAYOUT_4Q 68u /* bvh_width value of the quantised 64-byte BVH4 node format (SPEC §4.1) */
 #define PTO_BVH_LAYOUT_8Q 72u /* bvh_width value of the quantised 128-byte BVH8 node format (SPEC §4.1) */
+#define PTO_BVH_LAYOUT_8O 73u /* the same node bytes, children in octant slots, visited in the order slot ^ ray octant (SPEC §4.1) */
 
 typedef struct { uint32_t kind; float albedo[3]; float emission[3]; float roughness; float ior; uint32_t pad[3]; } pto_material; /* 48 B */
 typedef struct { float origin[3], forward[3], right[3], up[3]; float scale, cx, cy; uint32_t jitter; } pto_camera;              /* 64 B */

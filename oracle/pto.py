@@ -106,7 +106,7 @@ class Scene:
         self.keep["nodes"] = np.ascontiguousarray(nodes_bytes, np.uint8)
         self.keep["tris48"] = np.ascontiguousarray(tris_bytes, np.uint8)
         self.c.bvh_width = width
-        self.c.n_nodes = self.keep["nodes"].size // (64 if width == 68 else 128 if width == 72 else 32 * width)
+        self.c.n_nodes = self.keep["nodes"].size // (64 if width == 68 else 128 if width in (72, 73) else 32 * width)
         self.c.nodes, self.c.tris48 = _p(self.keep["nodes"]), _p(self.keep["tris48"])
 
     def build_own_bvh(self):

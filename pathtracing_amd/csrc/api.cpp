@@ -66,6 +66,14 @@ struct pt_context {
     DevBuf<float2> hit;
     DevBuf<uint32_t> sd, q_ext0, q_ext1, q_b[B_COUNT], counters, fb8;
     DevBuf<int32_t> stack_ovf;
+    // What k_generate would write at the start of every frame of a fused pipeline, kept from the first frame of its kind: the first
+    // extend queue (every shard's slots in slot order, holes for off-image pixels and sample-less streams) and the counter block
+    // that goes with it. A frame then starts with one 2.4 KB device copy instead of a kernel over every slot; the first extend
+    // launch reads q_init in place of q_ext[0] and zeroes the radiance sums of the slots it starts (kernels.hip, it == 0).
+    DevBuf<uint32_t> q_init, cnt_init;
+    struct InitKey { uint32_t w, h, rank, nranks, streams, first_spp, offset, n_slots, shard_cap; const void *q, *acc;
+                     bool operator==(const InitKey &o) const { return std::memcmp(this, &o, sizeof *this) == 0; } } init_key{};
+    bool init_valid = false;
     uint32_t *h_counts = nullptr; // pinned: kLag readbacks of the per-shard queue sizes (pt_tuning.readback = 1) + one copy of all counters
     uint4 *h_ring = nullptr, *d_ring = nullptr; // mapped pinned memory the extend kernels report their queue sizes to, kLag x kShards lines
                                                 // (host address, device address); PathState::host_ring
@@ -117,7 +125,7 @@ struct pt_scene {
     mutable std::vector<uint8_t> packed_nodes; // layouts PT_BVH_WIDTH_4Q / _8Q: the 64- / 128-byte nodes that are uploaded / read back
     bool device_packed = false;          // the blob was packed on the device (lbvh.hip build_lbvh_blob4q_device): the host copies below
     mutable bool host_mirror = true;     // (packed_nodes, bvh.tris) are fetched from the device the first time pt_scene_bvh_read wants them
-    bool quantised() const { return layout == PT_BVH_WIDTH_4Q || layout == PT_BVH_WIDTH_8Q; }
+    bool quantised() const { return layout == PT_BVH_WIDTH_4Q || layout == PT_BVH_WIDTH_8Q || layout == PT_BVH_WIDTH_8O; }
     const void *node_data() const { return quantised() ? (const void *)packed_nodes.data() : (const void *)bvh.slots.data(); }
     uint64_t node_bytes() const { return device_packed ? (uint64_t)bvh.n_nodes * 64u : quantised() ? packed_nodes.size() : bvh.slots.size() * sizeof(BvhSlot); }
     uint64_t n_blob_tris() const { return device_packed ? tri_mat.size() : bvh.tris.size(); }
@@ -270,6 +278,7 @@ void pt_context_destroy(pt_context *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->ray_o.release(); c->ray_d.release(); c->thr.release(); c->acc.release(); c->tiles.release(); c->fb.release(); c->hit.release();
     c->sd.release(); c->q_ext0.release(); c->q_ext1.release(); c->counters.release(); c->fb8.release(); c->stack_ovf.release();
+    c->q_init.release(); c->cnt_init.release();
     for (auto &q : c->q_b) q.release();
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
@@ -383,21 +392,23 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     // 15.0; soups of 100 / 400: - | 2.11 / 2.68 | 2.24 / 2.82 | 2.21 / 2.87. (Round 1 gave everything up to 256 triangles BVH8Q, on the
     // strength of the 12-triangle box alone, where it is one node.)
     if (bvh_width == PT_BVH_WIDTH_DEFAULT) bvh_width = s->tri_mat.size() <= 192 ? PT_BVH_WIDTH_2 : PT_BVH_WIDTH_4Q;
-    if (bvh_width != PT_BVH_WIDTH_2 && bvh_width != PT_BVH_WIDTH_4 && bvh_width != PT_BVH_WIDTH_4Q && bvh_width != PT_BVH_WIDTH_8Q)
-        return fail(c, PT_ERR_INVALID_ARGUMENT, "bvh_width must be one of PT_BVH_WIDTH_* (0, 2, 4, 68, 72)");
+    if (bvh_width != PT_BVH_WIDTH_2 && bvh_width != PT_BVH_WIDTH_4 && bvh_width != PT_BVH_WIDTH_4Q && bvh_width != PT_BVH_WIDTH_8Q && bvh_width != PT_BVH_WIDTH_8O)
+        return fail(c, PT_ERR_INVALID_ARGUMENT, "bvh_width must be one of PT_BVH_WIDTH_* (0, 2, 4, 68, 72, 73)");
     if (!s->have_cam) return fail(c, PT_ERR_INVALID_ARGUMENT, "no camera set");
     const uint32_t nt = (uint32_t)s->tri_mat.size(), ns = (uint32_t)s->sph_mat.size(), nm = (uint32_t)s->mats.size();
     if ((nt || ns) && nm == 0) return fail(c, PT_ERR_INVALID_ARGUMENT, "primitives but no materials");
     for (uint32_t i = 0; i < nt; ++i) if (s->tri_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "triangle %u: material id %u >= %u", i, s->tri_mat[i], nm);
     for (uint32_t i = 0; i < ns; ++i) if (s->sph_mat[i] >= nm) return fail(c, PT_ERR_INVALID_ARGUMENT, "sphere %u: material id %u >= %u", i, s->sph_mat[i], nm);
 
-    const uint32_t fan = bvh_width == PT_BVH_WIDTH_2 ? 2u : bvh_width == PT_BVH_WIDTH_8Q ? 8u : 4u;
+    const bool oct = bvh_width == PT_BVH_WIDTH_8O;
+    const uint32_t fan = bvh_width == PT_BVH_WIDTH_2 ? 2u : (bvh_width == PT_BVH_WIDTH_8Q || oct) ? 8u : 4u;
     static const bool timing = getenv("PTRT_TIMING") != nullptr; // developer aid: where a commit's time goes, on stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_phase = now();
     auto lap = [&](const char *what) { if (timing) fprintf(stderr, "ptrt commit: %-28s %8.2f ms\n", what, ms_since(t_phase)); t_phase = now(); };
     s->device_packed = false; s->host_mirror = true;
+    uint32_t unified_units = 0;
     if (lbvh && nt >= 2 && bvh_width == PT_BVH_WIDTH_4Q) {
         // the default layout is also packed on the device: nodes and triangle records are born in device memory
         HIP_TRY(c, hipSetDevice(c->device));
@@ -413,14 +424,14 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
         HIP_TRY(c, hipSetDevice(c->device));
         BinaryBvh bt;
         HIP_TRY(c, build_lbvh_device(c->stream, s->verts.data(), nt, bt));
-        build_bvh_from_binary(bt, s->verts.data(), s->tri_mat.data(), nt, fan, s->bvh);
-    } else build_bvh(s->verts.data(), s->tri_mat.data(), nt, fan, s->bvh);
+        build_bvh_from_binary(bt, s->verts.data(), s->tri_mat.data(), nt, fan, s->bvh, oct);
+    } else build_bvh(s->verts.data(), s->tri_mat.data(), nt, fan, s->bvh, oct);
     lap("hierarchy + blob");
     if (s->bvh.max_depth > 90) return fail(c, PT_ERR_INTERNAL, "BVH depth %u exceeds the supported 90", s->bvh.max_depth);
     s->layout = bvh_width;
     s->packed_nodes.clear();
     if (bvh_width == PT_BVH_WIDTH_4Q && !s->device_packed) quantize_bvh4(s->bvh, s->packed_nodes);
-    if (bvh_width == PT_BVH_WIDTH_8Q) quantize_bvh8(s->bvh, s->packed_nodes);
+    if (bvh_width == PT_BVH_WIDTH_8Q || oct) quantize_bvh8(s->bvh, s->packed_nodes);
     lap("quantise");
     if (!c) { s->committed = true; return PT_OK; } // detached scene: host-side blob only
 
@@ -444,10 +455,45 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
             std::memcpy(&rec[i * 16 + 15], &t.mat, 4);
         }
         lap("triangle records");
+        if (bvh_width == PT_BVH_WIDTH_4Q && getenv("PTRT_UNIFIED") && !rec.empty()) {
+            // EXPERIMENT (layout rows; tools/exp_order.py): nodes and triangle records in ONE array of 64-byte units, every
+            // node followed by the triangles of its leaf children, so that a bottom-level node and the first of its triangles share a
+            // 128-byte line. Refs count units; the kernels are unchanged (nodes and tris are the same base pointer). The device
+            // structure is then a renaming of the blob pt_scene_bvh_read hands out — same tree, same pictures.
+            const uint32_t nn = s->bvh.n_nodes, ntb = (uint32_t)s->bvh.tris.size();
+            std::vector<uint32_t> node_unit(nn), tri_unit(ntb);
+            uint32_t u = 0;
+            for (uint32_t i = 0; i < nn; ++i) {
+                node_unit[i] = u++;
+                for (int k = 0; k < 4; ++k) {
+                    int32_t r; std::memcpy(&r, &s->packed_nodes[(size_t)i * 64 + 16 + 4 * k], 4);
+                    if (r >= 0) continue;
+                    const uint32_t enc = (uint32_t)~r, first = enc >> 3, cnt = (enc & 7u) + 1u;
+                    for (uint32_t j = 0; j < cnt; ++j) tri_unit[first + j] = u++;
+                }
+            }
+            std::vector<uint8_t> uni((size_t)u * 64);
+            for (uint32_t i = 0; i < nn; ++i) {
+                uint8_t *nd = &uni[(size_t)node_unit[i] * 64];
+                std::memcpy(nd, &s->packed_nodes[(size_t)i * 64], 64);
+                for (int k = 0; k < 4; ++k) {
+                    int32_t r; std::memcpy(&r, nd + 16 + 4 * k, 4);
+                    if (r == 0x7fffffff) continue;
+                    if (r >= 0) r = (int32_t)node_unit[(uint32_t)r];
+                    else { const uint32_t enc = (uint32_t)~r; r = (int32_t)~((tri_unit[enc >> 3] << 3) | (enc & 7u)); }
+                    std::memcpy(nd + 16 + 4 * k, &r, 4);
+                }
+            }
+            for (uint32_t j = 0; j < ntb; ++j) std::memcpy(&uni[(size_t)tri_unit[j] * 64], &rec[(size_t)j * 16], 64);
+            HIP_TRY(c, s->d_nodes.ensure((size_t)u * 4));
+            HIP_TRY(c, hipMemcpy(s->d_nodes.p, uni.data(), uni.size(), hipMemcpyHostToDevice));
+            unified_units = u;
+        } else {
         if (!rec.empty()) HIP_TRY(c, hipMemcpy(s->d_tris.p, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice));
         lap("upload triangles");
+        }
     }
-    if (s->node_bytes()) HIP_TRY(c, hipMemcpy(s->d_nodes.p, s->node_data(), s->node_bytes(), hipMemcpyHostToDevice));
+    if (s->node_bytes() && !unified_units) HIP_TRY(c, hipMemcpy(s->d_nodes.p, s->node_data(), s->node_bytes(), hipMemcpyHostToDevice));
     }
     HIP_TRY(c, s->d_spheres.ensure((ns + 3u) & ~3u)); // the kernels read the list four spheres (one 64-byte scalar load) at a time
     HIP_TRY(c, s->d_sph_mat.ensure(ns));
@@ -462,6 +508,7 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     DeviceScene &d = s->ds;
     d.nodes = s->d_nodes.p; d.tris = s->d_tris.p; d.spheres = s->d_spheres.p; d.sph_mat = s->d_sph_mat.p; d.mats = s->d_mats.p;
     d.n_nodes = s->bvh.n_nodes; d.n_tris = nt; d.n_spheres = ns; d.n_mats = nm;
+    if (unified_units) { d.tris = d.nodes; d.n_tris = unified_units; } // (experiment) triangle refs count units of the one array; sphere refs follow them
     for (int k = 0; k < 3; ++k) d.sky[k] = s->sky[k];
     d.bvh_width = bvh_width;
     d.cam = s->cam;
@@ -634,11 +681,32 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
 
     const DeviceScene &sc = s->ds;
     hipStream_t q = c->stream;
-    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * kCntTotalWords, q));
-    HIP_TRY(c, hipEventRecord(c->ev_start, q));
     // the fused one-ray-per-lane and lane-packing kernels build a slot's initial state in registers in their first launch; k_shade
     // (split pipelines) and the pooled kernel read it from memory
-    HIP_TRY(c, launch_generate(q, sc, ps, fp, split_kernels || forced_choice == (uint32_t)EXT_POOL));
+    const bool full_state = split_kernels || forced_choice == (uint32_t)EXT_POOL;
+    if (full_state) {
+        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * kCntTotalWords, q));
+        HIP_TRY(c, hipEventRecord(c->ev_start, q));
+        HIP_TRY(c, launch_generate(q, sc, ps, fp, true));
+    } else {
+        // k_generate's output depends on the frame's geometry only (which slots exist: size, rank, streams, whether every stream has
+        // a sample): made once per geometry, then a frame starts with a copy of the counter block (pt_context::q_init)
+        HIP_TRY(c, c->q_init.ensure(q_entries)); HIP_TRY(c, c->cnt_init.ensure(kCntTotalWords));
+        pt_context::InitKey key;
+        std::memset(&key, 0, sizeof key);
+        key.w = p->width; key.h = p->height; key.rank = p->rank; key.nranks = nranks; key.streams = streams; key.first_spp = std::min(p->spp, streams);
+        key.offset = p->sample_offset % streams; key.n_slots = n_slots; key.shard_cap = shard_cap; key.q = c->q_init.p; key.acc = c->acc.p;
+        if (!c->init_valid || !(key == c->init_key)) {
+            c->init_valid = false;
+            HIP_TRY(c, hipMemsetAsync(c->cnt_init.p, 0, sizeof(uint32_t) * kCntTotalWords, q));
+            PathState pt = ps;
+            pt.counters = c->cnt_init.p; pt.q_ext[0] = c->q_init.p;
+            HIP_TRY(c, launch_generate(q, sc, pt, fp, false)); // also zeroes every slot's sum (slots that never hold a path stay zero from here on)
+            c->init_key = key; c->init_valid = true;
+        }
+        HIP_TRY(c, hipEventRecord(c->ev_start, q));
+        HIP_TRY(c, hipMemcpyAsync(c->counters.p, c->cnt_init.p, sizeof(uint32_t) * kCntTotalWords, hipMemcpyDeviceToDevice, q));
+    }
 
     // Wavefront loops. Shards never exchange slots, so the 64 shards are split into `n_loops` independent loops, each on
     // its own HIP stream: the tail of one group's launch (its last wavefronts draining) is filled by the other's launch
@@ -700,6 +768,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
             const uint32_t it = L.iters;
             PathState pg = ps;
             pg.shard_base = L.base; pg.shard_count = per_group;
+            if (it == 0u && !full_state) pg.q_ext[0] = c->q_init.p; // the frame's first queue is the same every frame: read, never written
             if (ext_choice == 0u) pg.finish_below = 0u; // while the extend kernel is still being probed, iterations stay comparable
             hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
             if (profile) {

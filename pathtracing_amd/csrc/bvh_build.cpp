@@ -177,14 +177,19 @@ int32_t build_parallel(Builder &B, uint32_t n, uint32_t serial_below = 1u << 16,
 
 // Binary tree (tmp nodes, leaves = ranges of idx) -> blob: collapse to `width` children per node by opening the child of
 // largest area, lay nodes out breadth-first, emit triangles in leaf order, compute depth and the worst-case stack need.
+// octant_slots (width 8, layout BVH8O): a node's children are placed in the slot whose index names the corner of the node they sit in
+// — bit k of the slot = child lies towards +axis k — so that `slot ^ (sign bits of the ray direction)` is a front-to-back order
+// and the traversal needs no distance sort (the child-to-slot assignment of Ylitie, Karras & Laine, "Efficient incoherent ray
+// traversal on GPUs through compressed wide BVHs", HPG 2017: greedy on the projection of the child's centre onto the slot's diagonal).
 void emit_blob(const std::vector<Tmp> &tn, int32_t root, const std::vector<uint32_t> &idx, const float *verts9, const uint32_t *mats,
-               uint32_t n_tris, uint32_t width, BvhBlob &out)
+               uint32_t n_tris, uint32_t width, BvhBlob &out, bool octant_slots = false)
 {
-    struct Pending { int32_t kids[8]; int nk; }; // width <= 8
+    struct Pending { int32_t kids[8]; int nk; }; // width <= 8; kids[c] < 0: empty slot (octant_slots leaves holes anywhere)
     std::vector<Pending> pend;
     pend.reserve(tn.size());
     auto expand = [&](int32_t t) { // children of the output node made from tmp node t
         Pending p; p.nk = 0;
+        for (int i = 0; i < 8; ++i) p.kids[i] = -1;
         if (tn[t].count) { p.kids[p.nk++] = t; return p; } // (root is a leaf) single child
         p.kids[p.nk++] = tn[t].left; p.kids[p.nk++] = tn[t].right;
         while (p.nk < (int)width) {
@@ -196,6 +201,29 @@ void emit_blob(const std::vector<Tmp> &tn, int32_t root, const std::vector<uint3
             for (int i = p.nk; i > best + 1; --i) p.kids[i] = p.kids[i - 1];
             p.kids[best] = tn[c].left; p.kids[best + 1] = tn[c].right; p.nk++;
         }
+        if (octant_slots && width == 8) {
+            float cen[8][3], mid[3];
+            Box all; all.reset();
+            for (int i = 0; i < p.nk; ++i) all.grow(tn[p.kids[i]].box);
+            for (int a = 0; a < 3; ++a) mid[a] = 0.5f * (all.lo[a] + all.hi[a]);
+            for (int i = 0; i < p.nk; ++i) for (int a = 0; a < 3; ++a) cen[i][a] = 0.5f * (tn[p.kids[i]].box.lo[a] + tn[p.kids[i]].box.hi[a]) - mid[a];
+            int32_t placed[8]; for (int sl = 0; sl < 8; ++sl) placed[sl] = -1;
+            bool done[8] = {};
+            for (int round = 0; round < p.nk; ++round) { // greedy: the (child, free slot) pair of largest projection; ties: lowest child, lowest slot
+                int bc = -1, bs = -1; float bv = -kInf;
+                for (int i = 0; i < p.nk; ++i) {
+                    if (done[i]) continue;
+                    for (int sl = 0; sl < 8; ++sl) {
+                        if (placed[sl] >= 0) continue;
+                        const float v = (sl & 1 ? cen[i][0] : -cen[i][0]) + (sl & 2 ? cen[i][1] : -cen[i][1]) + (sl & 4 ? cen[i][2] : -cen[i][2]);
+                        if (v > bv) { bv = v; bc = i; bs = sl; }
+                    }
+                }
+                placed[bs] = p.kids[bc]; done[bc] = true;
+            }
+            for (int sl = 0; sl < 8; ++sl) p.kids[sl] = placed[sl];
+            p.nk = 8;
+        } else for (int i = p.nk; i < 8; ++i) p.kids[i] = -1;
         return p;
     };
     pend.push_back(expand(root));
@@ -208,6 +236,7 @@ void emit_blob(const std::vector<Tmp> &tn, int32_t root, const std::vector<uint3
         BvhSlot s[8];
         for (uint32_t c = 0; c < width; ++c) { std::memset(&s[c], 0, sizeof(BvhSlot)); s[c].ref = kEmpty; }
         for (int c = 0; c < p.nk; ++c) {
+            if (p.kids[c] < 0) continue;
             const Tmp &k = tn[p.kids[c]];
             for (int a = 0; a < 3; ++a) { s[c].lo[a] = k.box.lo[a]; s[c].hi[a] = k.box.hi[a]; }
             if (k.count) {
@@ -332,7 +361,7 @@ void reorder_blob(BvhBlob &b, uint32_t mode)
 
 } // namespace
 
-void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out)
+void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out, bool octant_slots)
 {
     const auto t0 = std::chrono::steady_clock::now();
     out = BvhBlob{};
@@ -354,7 +383,7 @@ void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint3
     }
     Builder B(prims, idx);
     const int32_t root = build_parallel(B, n_tris);
-    emit_blob(B.nodes, root, idx, verts9, mats, n_tris, width, out);
+    emit_blob(B.nodes, root, idx, verts9, mats, n_tris, width, out, octant_slots);
     if (const char *e = getenv("PTRT_NODE_ORDER")) reorder_blob(out, (uint32_t)atoi(e)); // developer aid: layout experiments (tools/exp_order.py)
     out.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -369,7 +398,7 @@ void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint3
 #define PT_LBVH_CLUSTER 32
 #endif
 constexpr uint32_t kClusterTris = PT_LBVH_CLUSTER; // 0: no SAH storey, the LBVH as it is
-void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out)
+void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out, bool octant_slots)
 {
     const auto t0 = std::chrono::steady_clock::now();
     out = BvhBlob{};
@@ -434,7 +463,7 @@ void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint3
         tn[w.at] = t;
     }
     const auto t1 = std::chrono::steady_clock::now();
-    emit_blob(tn, root, bt.order, verts9, mats, n_tris, width, out);
+    emit_blob(tn, root, bt.order, verts9, mats, n_tris, width, out, octant_slots);
     if (getenv("PTRT_TIMING")) // developer aid
         fprintf(stderr, "ptrt commit: lbvh device %.2f ms, cut + SAH top + conversion %.2f ms, emit_blob %.2f ms\n", bt.device_ms,
                 std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());

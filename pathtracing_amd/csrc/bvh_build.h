@@ -19,7 +19,8 @@ struct BvhBlob {
 };
 
 // verts9: 9 floats per triangle; mats may be null (all 0). width: 2, 4 or 8.
-void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out);
+// octant_slots (width 8): children placed in slots by the octant of the node they sit in (layout BVH8O, docs/SPEC.md §4.1)
+void build_bvh(const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out, bool octant_slots = false);
 
 // Binary LBVH as the device builder (lbvh.hip) returns it: n leaves of one triangle each in Morton order, n-1 internal nodes, node 0 = root.
 struct BinaryBvh {
@@ -30,7 +31,7 @@ struct BinaryBvh {
     double device_ms = 0.0;             // upload + kernels + sort + read-back
 };
 // pack a device-built binary tree into a width-2/4 blob (subtrees of <= 4 triangles become leaves)
-void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out);
+void build_bvh_from_binary(const BinaryBvh &bt, const float *verts9, const uint32_t *mats, uint32_t n_tris, uint32_t width, BvhBlob &out, bool octant_slots = false);
 
 // Binned-SAH binary tree over n boxes (6 floats each), one box per leaf: children >= 0 internal node, < 0 leaf ~i (box i); node k's box in
 // node_boxes6. Used for the top storey of the GPU builder (a few thousand LBVH clusters).

@@ -174,9 +174,9 @@ __global__ void __launch_bounds__(kBlock) k_reference_sphere(uint32_t w, uint32_
 //             Beyond the caches a node visit costs the memory system one 128-byte line whether 64 or 96 bytes of it are
 //             used (tools/ubench/gather_rows.hip), and an 8-wide tree needs fewer visits. Keys keep 3 bits for the slot.
 template <int L>
-PT_DEV constexpr int node_rows() { return (L == PT_BVH_WIDTH_4 || L == PT_BVH_WIDTH_8Q) ? 8 : 4; }
+PT_DEV constexpr int node_rows() { return (L == PT_BVH_WIDTH_4 || L == PT_BVH_WIDTH_8Q || L == PT_BVH_WIDTH_8O) ? 8 : 4; }
 template <int L>
-PT_DEV constexpr int fanout() { return L == PT_BVH_WIDTH_2 ? 2 : L == PT_BVH_WIDTH_8Q ? 8 : 4; }
+PT_DEV constexpr int fanout() { return L == PT_BVH_WIDTH_2 ? 2 : (L == PT_BVH_WIDTH_8Q || L == PT_BVH_WIDTH_8O) ? 8 : 4; }
 
 template <int L>
 PT_DEV void visit_node_keys(const float4 *__restrict__ nd, float4 r0, float4 r1, float4 r2, float4 r3, const RaySetup &rs, float t_best,
@@ -266,6 +266,56 @@ PT_DEV void visit_node_keys(const float4 *__restrict__ nd, float4 r0, float4 r1,
             key[c] = hb ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
         }
     }
+}
+
+// L = 8O: the node bytes of 8Q, but the builder has placed every child in the slot that names its corner of the node (bit k of the
+// slot = towards +axis k), so `slot ^ octant` (octant bit k = the ray runs towards -axis k) is a front-to-back order known without
+// looking at the distances: no keys, no sorting network. Returns the children in VISIT order: bit p of `hits` / ref[p] = the child in
+// slot p ^ octant. The xor permutation is three rounds of conditional pair swaps on the refs and three bit-swizzles on the hit mask.
+PT_DEV void visit_node_oct8(const float4 *__restrict__ nd, float4 r0, float4 r1, float4 r2, float4 r3, const RaySetup &rs, float t_best,
+                            uint32_t &hits, int32_t (&ref)[8])
+{
+    const float4 r4 = nd[4], r5 = nd[5];
+    const uint32_t eb = __float_as_uint(r0.w);
+    const float sx = __uint_as_float((eb & 0xffu) << 23), sy = __uint_as_float(((eb >> 8) & 0xffu) << 23), sz = __uint_as_float(((eb >> 16) & 0xffu) << 23);
+    const uint32_t q[6][2] = { { __float_as_uint(r3.x), __float_as_uint(r3.y) }, { __float_as_uint(r3.z), __float_as_uint(r3.w) },
+                               { __float_as_uint(r4.x), __float_as_uint(r4.y) }, { __float_as_uint(r4.z), __float_as_uint(r4.w) },
+                               { __float_as_uint(r5.x), __float_as_uint(r5.y) }, { __float_as_uint(r5.z), __float_as_uint(r5.w) } };
+    ref[0] = __float_as_int(r1.x); ref[1] = __float_as_int(r1.y); ref[2] = __float_as_int(r1.z); ref[3] = __float_as_int(r1.w);
+    ref[4] = __float_as_int(r2.x); ref[5] = __float_as_int(r2.y); ref[6] = __float_as_int(r2.z); ref[7] = __float_as_int(r2.w);
+    const bool ng[3] = { rs.inv.x < 0.f, rs.inv.y < 0.f, rs.inv.z < 0.f };
+    const float qa[3] = { sx * rs.inv.x, sy * rs.inv.y, sz * rs.inv.z };
+    const float qb[3] = { fma_(r0.x, rs.inv.x, rs.noi.x), fma_(r0.y, rs.inv.y, rs.noi.y), fma_(r0.z, rs.inv.z, rs.noi.z) };
+    uint32_t qn[3][2], qf[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) { qn[k][w] = ng[k] ? q[3 + k][w] : q[k][w]; qf[k][w] = ng[k] ? q[k][w] : q[3 + k][w]; }
+    uint32_t m = 0u; // bit c: slot c is hit
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int w = c >> 2, sh = 8 * (c & 3);
+        float tnk[3], tfk[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            tnk[k] = fma_((float)((qn[k][w] >> sh) & 0xffu), qa[k], qb[k]);
+            tfk[k] = fma_((float)((qf[k][w] >> sh) & 0xffu), qa[k], qb[k]);
+        }
+        const float tn = fmax_(fmax_(tnk[0], tnk[1]), fmax_(tnk[2], 0.0f));
+        const float tf = fmin_(fmin_(tfk[0], tfk[1]), fmin_(tfk[2], t_best)) * 1.0000004f;
+        m |= (tn <= tf && ref[c] != PT_BVH_EMPTY) ? (1u << c) : 0u;
+    }
+    // position p holds slot p ^ octant
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int d = 1 << b;
+        const uint32_t lo = b == 0 ? 0x55u : b == 1 ? 0x33u : 0x0Fu;
+        m = ng[b] ? (((m & lo) << d) | ((m >> d) & lo)) : m;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (!(i & d)) { const int32_t a = ref[i], bb = ref[i | d]; ref[i] = ng[b] ? bb : a; ref[i | d] = ng[b] ? a : bb; }
+    }
+    hits = m;
 }
 
 // Sorting network over (key, ref), ascending key, in two halves: after sort_head the nearest hit child is in slot 0 (so its
@@ -500,10 +550,43 @@ PT_DEV bool want_compact(const PathState &ps, uint32_t len, uint32_t n_alive, ui
     return forced || (sticky && len < ps.shard_cap) || (float)predicted < ps.compact_below * (float)len;
 }
 
-PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint32_t *q_next, uint32_t gid, uint32_t total, bool alive,
-                       uint32_t slot, bool compact)
+// EXPERIMENT (-DPT_REPACK_SORT=1; DESIGN.md §4 "coherence-ordered re-packing"): at a re-pack a wave appends its survivors ordered by a
+// 6-bit key — octant of the ray direction, octant of the origin about the scene's centre — instead of by lane. Rank of a lane among
+// the wave's survivors by (key, lane), from ballots alone: walking the key bits from the top, `eq` keeps the lanes that agree with
+// mine so far and `lt` collects those that have a 0 where I have a 1.
+#ifndef PT_REPACK_SORT
+#define PT_REPACK_SORT 0
+#endif
+PT_DEV uint32_t wave_rank_by_key(bool pred, uint32_t key)
 {
-    if (compact) wave_push(&ps.counters[cnt_ext_index(cnext, shard)], q_next, alive, slot);
+    uint64_t eq = __ballot(pred), lt = 0;
+#pragma unroll
+    for (int b = 5; b >= 0; --b) {
+        const bool one = (key >> b) & 1u;
+        const uint64_t bal = __ballot(pred && one);
+        if (one) lt |= eq & ~bal;
+        eq &= one ? bal : ~bal;
+    }
+    const uint64_t below = (1ull << lane_id()) - 1ull;
+    return (uint32_t)__popcll(lt) + (uint32_t)__popcll(eq & below);
+}
+PT_DEV void wave_push_sorted(uint32_t *counter, uint32_t *queue, bool pred, uint32_t value, uint32_t key)
+{
+    const uint64_t m = __ballot(pred);
+    if (m == 0) return;
+    const uint32_t rank = wave_rank_by_key(pred, key);
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (pred) queue[base + rank] = value;
+}
+
+PT_DEV void queue_next(const PathState &ps, uint32_t shard, uint32_t cnext, uint32_t *q_next, uint32_t gid, uint32_t total, bool alive,
+                       uint32_t slot, bool compact, uint32_t sort_key = 0u)
+{
+    if (compact && PT_REPACK_SORT) wave_push_sorted(&ps.counters[cnt_ext_index(cnext, shard)], q_next, alive, slot, sort_key);
+    else if (compact) wave_push(&ps.counters[cnt_ext_index(cnext, shard)], q_next, alive, slot);
     else {
         if (gid < total) at(q_next, gid) = alive ? slot : kInvalidSlot;
         if (gid == 0) ps.counters[cnt_ext_index(cnext, shard)] = total;
@@ -577,6 +660,30 @@ PT_DEV void node_visit_rows(const float4 *__restrict__ base, float4 r0, float4 r
 {
     constexpr int N = fanout<L>();
     const bool deep = __any((int)(sp + (uint32_t)(N - 1) > kStackLds)) != 0;
+    if constexpr (L == PT_BVH_WIDTH_8O) { // children arrive in visit order, hits and misses mixed: walk them far to near, the nearest hit stays in `cur`
+        uint32_t hits;
+        int32_t ref[N];
+        visit_node_oct8(base, r0, r1, r2, r3, rs, t_best, hits, ref);
+        int32_t prev = PT_BVH_EMPTY;
+        if (!deep) {
+#pragma unroll
+            for (int p = N - 1; p >= 0; --p) {
+                const bool h = (hits >> p) & 1u;
+                k.lds[sp * k.stride + k.tid] = prev;
+                sp += (h && prev != PT_BVH_EMPTY) ? 1u : 0u;
+                prev = h ? ref[p] : prev;
+            }
+            if (prev != PT_BVH_EMPTY) cur = prev;
+            else if (sp) { --sp; cur = k.lds[sp * k.stride + k.tid]; }
+            else cur = PT_BVH_EMPTY;
+        } else {
+#pragma unroll
+            for (int p = N - 1; p >= 0; --p)
+                if ((hits >> p) & 1u) { if (prev != PT_BVH_EMPTY) push_slow(k, sp, prev); prev = ref[p]; }
+            cur = prev != PT_BVH_EMPTY ? prev : pop_slow(k, sp);
+        }
+        return;
+    }
     uint32_t key[N];
     int32_t ref[N];
     visit_node<L>(base, r0, r1, r2, r3, rs, t_best, key, ref); // keys sorted ascending, misses = 0xFFFFFFFF at the end
@@ -674,7 +781,10 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     if (active) {
         const PathState &ps = cold().ps;
         if (FUSE == SHADE_NONE) { r.o = xyz(at(ps.ray_o, slot)); r.d = xyz(at(ps.ray_d, slot)); }
-        else if (it == 0u) path_init(cold().sc, cold().fp, slot, r); // k_generate left the state to this launch (launch_generate)
+        else if (it == 0u) { // the frame's first launch makes the state of its slots itself (api.cpp: q_init) and starts their radiance sums
+            path_init(cold().sc, cold().fp, slot, r);
+            if (!cold().fp.accumulate) at(ps.acc, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         else path_load(ps, slot, r);
     }
     bool alive = active;
@@ -763,7 +873,10 @@ __global__ void __launch_bounds__(kExtBlock) __attribute__((amdgpu_waves_per_eu(
     }
     if (FUSE != SHADE_NONE) {
         if (alive) path_store(ps, slot, r);
-        queue_next(ps, shard, cnext, &at(ps.q_ext[parity ^ 1u], qbase), gid, n, alive, slot, do_compact);
+        uint32_t sort_key = 0u;
+        if (PT_REPACK_SORT) sort_key = (r.d.x < 0.f ? 32u : 0u) | (r.d.y < 0.f ? 16u : 0u) | (r.d.z < 0.f ? 8u : 0u) |
+                                       (r.o.x < 0.f ? 4u : 0u) | (r.o.y < 0.f ? 2u : 0u) | (r.o.z < 0.f ? 1u : 0u);
+        queue_next(ps, shard, cnext, &at(ps.q_ext[parity ^ 1u], qbase), gid, n, alive, slot, do_compact, sort_key);
         if (wave_rays && lane_id() == 0u) atomicAdd(traced_counter(ps, cnext, shard), (unsigned long long)wave_rays);
     }
 }
@@ -905,7 +1018,10 @@ k_extend_packed(ExtArgs a)
                 if (FUSE != SHADE_NONE && !do_compact) q_next[pos] = kInvalidSlot;
             } else if (pull) {
                 if (FUSE == SHADE_NONE) { o = xyz(at(cold().ps.ray_o, slot)); d = xyz(at(cold().ps.ray_d, slot)); }
-                else if (it == 0u) path_init(cold().sc, cold().fp, slot, r); // see k_extend
+                else if (it == 0u) { // see k_extend
+                    path_init(cold().sc, cold().fp, slot, r);
+                    if (!cold().fp.accumulate) at(cold().ps.acc, slot) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
                 else path_load(cold().ps, slot, r);
                 budget = budget0;
                 start_ray();
@@ -933,7 +1049,28 @@ k_extend_packed(ExtArgs a)
                     return s_stack[sp * 64u + lane];
                 };
                 if (++steps > (1u << 22)) { atomicOr(&cold().ps.counters[kCntError], 2u); cur = PT_BVH_EMPTY; }
-                else if (inner) {
+                else if (inner && L == PT_BVH_WIDTH_8O) { // octant order: see node_visit_rows
+                    uint32_t hits;
+                    int32_t ref[N];
+                    if constexpr (L == PT_BVH_WIDTH_8O) visit_node_oct8(base, r0, r1, r2, r3, rs, h.t, hits, ref);
+                    if (COUNT) c_nodes++;
+                    int32_t prev = PT_BVH_EMPTY;
+                    if (!deep) {
+#pragma unroll
+                        for (int p = N - 1; p >= 0; --p) {
+                            const bool hp = (hits >> p) & 1u;
+                            s_stack[sp * 64u + lane] = prev;
+                            sp += (hp && prev != PT_BVH_EMPTY) ? 1u : 0u;
+                            prev = hp ? ref[p] : prev;
+                        }
+                        cur = prev != PT_BVH_EMPTY ? prev : pop_fast();
+                    } else {
+#pragma unroll
+                        for (int p = N - 1; p >= 0; --p)
+                            if ((hits >> p) & 1u) { if (prev != PT_BVH_EMPTY) push(prev); prev = ref[p]; }
+                        cur = prev != PT_BVH_EMPTY ? prev : pop();
+                    }
+                } else if (inner) {
                     uint32_t key[N];
                     int32_t ref[N];
                     visit_node<L>(base, r0, r1, r2, r3, rs, h.t, key, ref);
@@ -1310,6 +1447,7 @@ hipError_t launch_extend(hipStream_t s, const DeviceScene &sc, const PathState &
     case PT_BVH_WIDTH_4:  count ? extend_lc<PT_BVH_WIDTH_4, true>(s, grid, a, kernel, fuse) : extend_lc<PT_BVH_WIDTH_4, false>(s, grid, a, kernel, fuse); break;
     case PT_BVH_WIDTH_4Q: count ? extend_lc<PT_BVH_WIDTH_4Q, true>(s, grid, a, kernel, fuse) : extend_lc<PT_BVH_WIDTH_4Q, false>(s, grid, a, kernel, fuse); break;
     case PT_BVH_WIDTH_8Q: count ? extend_lc<PT_BVH_WIDTH_8Q, true>(s, grid, a, kernel, fuse) : extend_lc<PT_BVH_WIDTH_8Q, false>(s, grid, a, kernel, fuse); break;
+    case PT_BVH_WIDTH_8O: count ? extend_lc<PT_BVH_WIDTH_8O, true>(s, grid, a, kernel, fuse) : extend_lc<PT_BVH_WIDTH_8O, false>(s, grid, a, kernel, fuse); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -23,5 +23,8 @@ else:
     r.Params = P.make_params(W, H, spp=spp, max_depth=depth, streams=8, rank=0, nranks=nranks)
 for _ in range(frames):
     st = r.Render(0.0)
+import json
+key = ["sphere", 0, W, H, 1, 0, 0, 0] if scene == "sphere" else [{"tess": "cornell_tess", "glass": "cornell_glass"}.get(scene, scene), kinds[scene][1], W, H, spp, depth, 8, int(r.BvhInfo().width)]
 print(f"{scene} {W}x{H} {spp} spp: {st.gpu_ms:.3f} ms, {st.rays} rays, {st.iterations} launches, kernel {int(st.reserved[0])}", flush=True)
+print("workload_key " + json.dumps(key), flush=True)
 r.Dispose()

@@ -5,7 +5,8 @@ out=$1; orders=$2; scene=${3:-tess}; spp=${4:-64}; kern=${5:-1}
 export TMPDIR=/tmp
 mkdir -p "$out"
 for o in $orders; do
-  export PTRT_NODE_ORDER=$o
+  export PTRT_NODE_ORDER=${o#u}
+  if [ "${o#u}" != "$o" ]; then export PTRT_UNIFIED=1; else unset PTRT_UNIFIED; fi
   timeout -k 10 180 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum --output-format csv -d "$out/${scene}_o$o" -o p -- python3 tools/one_frame.py $scene $spp $kern 1 > "$out/${scene}_o$o.log" 2>&1 || { echo "order $o failed"; tail -3 "$out/${scene}_o$o.log"; }
   timeout -k 10 180 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum --output-format csv -d "$out/${scene}_t$o" -o p -- python3 tools/one_frame.py $scene $spp $kern 1 > "$out/${scene}_t$o.log" 2>&1 || { echo "order $o (tcp) failed"; }
   python3 - "$out" "$scene" "$o" <<'PY'
