@@ -1,9 +1,10 @@
 // ptrt_cli — headless counterpart of Program.cs / App.Run (RayTracing/Program.cs:1-9, App.cs:15-21):
 // build a renderer, render N frames, write the image the reference would have shown in its window.
 //   ptrt_cli [--scene reference|cornell|glass|soup|tess] [--detail N] [--size WxH] [--spp N] [--depth N]
-//            [--frames N] [--ppm out.ppm] [--pfm out.pfm] [--gpus N] [--virtual 1]
+//            [--frames N] [--ppm out.ppm] [--pfm out.pfm] [--gpus N] [--virtual 0|1|2]
 // --gpus N: the frame's tiles over N devices of this node, one RCCL gather per frame (pt_comm); with --virtual 1 the N ranks are
-// rendered one after the other on device 0 (rehearsal of the partition on a single GPU).
+// rendered one after the other on device 0 (rehearsal of the partition on a single GPU); with --virtual 2 every rank has its own
+// context on device 0, the ranks render concurrently (one host thread each) and exchange their tiles by device copies.
 #include "ptrt_host.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -34,7 +35,7 @@ int main(int argc, char **argv)
         const uint32_t kind = scene == "cornell" ? PT_SCENE_CORNELL : scene == "glass" ? PT_SCENE_CORNELL_GLASS
                             : scene == "soup" ? PT_SCENE_TRIANGLE_SOUP : PT_SCENE_CORNELL_TESS;
         if (gpus > 1 && scene != "reference") {
-            multi.reset(new ptrt_host::MultiRenderer(gpus, w, h, virt != 0));
+            multi.reset(new ptrt_host::MultiRenderer(gpus, w, h, (int)virt));
             multi->Init();
             multi->LoadSyntheticScene(kind, detail);
             multi->Params.spp = spp; multi->Params.max_depth = depth;

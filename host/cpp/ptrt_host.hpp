@@ -95,7 +95,9 @@ public:
     pt_render_params Params{};
     std::vector<pt_stats> LastStats;
 
-    MultiRenderer(uint32_t n_ranks, uint32_t width, uint32_t height, bool virtual_ranks = false) : n_(n_ranks), virtual_(virtual_ranks)
+    // mode 0: one device per rank, one RCCL gather per frame; 1: virtual ranks (one context renders the ranks one after the other);
+    // 2: one context per rank, all on device 0, rendered concurrently, tiles exchanged by device copies (PT_COMM_COPY_EXCHANGE)
+    MultiRenderer(uint32_t n_ranks, uint32_t width, uint32_t height, int mode = 0) : n_(n_ranks), virtual_(mode == 1), one_device_(mode == 2)
     {
         const uint32_t n_ctx = virtual_ ? 1u : n_;
         for (uint32_t i = 0; i < n_ctx; ++i) r_.emplace_back(new Renderer(width, height));
@@ -105,7 +107,7 @@ public:
     ~MultiRenderer() { Dispose(); }
     void Init()
     {
-        for (size_t i = 0; i < r_.size(); ++i) r_[i]->Init((int)i);
+        for (size_t i = 0; i < r_.size(); ++i) r_[i]->Init(one_device_ ? 0 : (int)i);
     }
     void LoadSyntheticScene(uint32_t kind, uint32_t detail = 0, uint32_t seed = 0x5EED0001u, uint32_t bvh_width = 0)
     {
@@ -115,7 +117,7 @@ public:
         for (uint32_t i = 0; i < n_; ++i) ctxs[i] = r_[virtual_ ? 0 : i]->Context();
         if (comm_) pt_comm_destroy(comm_);
         comm_ = nullptr;
-        check(pt_comm_create(ctxs.data(), n_, 0, 0, &comm_));
+        check(pt_comm_create(ctxs.data(), n_, 0, one_device_ ? PT_COMM_COPY_EXCHANGE : 0u, &comm_));
     }
     void Render(float)
     {
@@ -135,7 +137,7 @@ public:
 
 private:
     uint32_t n_;
-    bool virtual_;
+    bool virtual_, one_device_;
     std::vector<std::unique_ptr<Renderer>> r_;
     pt_comm *comm_ = nullptr;
 };

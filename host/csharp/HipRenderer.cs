@@ -114,10 +114,14 @@ public unsafe class HipMultiRenderer : IDisposable
     public PtRenderParams Params;
     public PtStats[] LastStats;
 
-    public HipMultiRenderer(int gpus, uint width = 1920, uint height = 1080)
+    private readonly uint _commFlags;
+
+    // oneDevice: every rank gets its own context on device 0 and the tiles are exchanged by device copies (PtCommFlags.CopyExchange)
+    public HipMultiRenderer(int gpus, uint width = 1920, uint height = 1080, bool oneDevice = false)
     {
+        _commFlags = oneDevice ? (uint)PtCommFlags.CopyExchange : 0u;
         _r = new HipRenderer[gpus];
-        for (int i = 0; i < gpus; i++) { _r[i] = new HipRenderer(width, height); _r[i].Init(i); }
+        for (int i = 0; i < gpus; i++) { _r[i] = new HipRenderer(width, height); _r[i].Init(oneDevice ? 0 : i); }
         Params = _r[0].Params;
         LastStats = new PtStats[gpus];
     }
@@ -129,7 +133,7 @@ public unsafe class HipMultiRenderer : IDisposable
         void** ctxs = stackalloc void*[_r.Length];
         for (int i = 0; i < _r.Length; i++) ctxs[i] = _r[i].Context;
         if (_comm != null) Ptrt.pt_comm_destroy(_comm);
-        void* c; Ptrt.Check(Ptrt.pt_comm_create(ctxs, (uint)_r.Length, 0, 0, &c)); _comm = c;
+        void* c; Ptrt.Check(Ptrt.pt_comm_create(ctxs, (uint)_r.Length, 0, _commFlags, &c)); _comm = c;
     }
 
     public void Render(float delta)

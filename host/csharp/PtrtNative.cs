@@ -12,6 +12,7 @@ public enum PtMode : uint { ReferenceSphere = 0, PathTrace = 1 }
 public enum PtMaterialKind : uint { Lambert = 0, Metal = 1, Dielectric = 2 }
 public enum PtSceneKind : uint { Cornell = 0, CornellGlass = 1, TriangleSoup = 2, CornellTess = 3 }
 [Flags] public enum PtFlags : uint { ProfileKernels = 1, CountVisits = 2, ExtendPacked = 4, ExtendSimple = 8, Accumulate = 16, BucketSpecular = 32, SplitKernels = 64, ExtendPool = 128 }
+[Flags] public enum PtCommFlags : uint { ForceRccl = 1, CopyExchange = 2 }
 public enum PtBvhWidth : uint { Default = 0, W2 = 2, W4 = 4, W4Q = 68, W8Q = 72, W8O = 73, BuildLbvh = 0x100 }
 
 [StructLayout(LayoutKind.Sequential)] public unsafe struct PtDeviceDesc { public int device_ordinal; public void* stream; public uint flags; public uint reserved; }

@@ -235,9 +235,14 @@ pt_status pt_assemble_tiles(pt_context *ctx, const pt_render_params *params, con
  * context ("virtual ranks": rehearsal of the partition on a single GPU) are rendered one after the other and staged by device
  * copies. A rank's tile buffer (pt_tiles_device_ptr) belongs to the library between pt_render and the end of the exchange. */
 typedef struct pt_comm pt_comm;
-enum { PT_COMM_FORCE_RCCL = 1u }; /* pt_comm_create flags: use the RCCL path even for a single rank (plumbing check on one GPU) */
+enum {
+    PT_COMM_FORCE_RCCL = 1u,    /* pt_comm_create flags: use the RCCL path even for a single rank (plumbing check on one GPU) */
+    PT_COMM_COPY_EXCHANGE = 2u  /* no RCCL: every rank's tile block reaches the root by a device copy on the rank's own stream (a peer copy over
+                                   xGMI between devices). Also lifts the one-context-per-device rule: N contexts on ONE device render
+                                   concurrently, one host thread each — the multi-context code path as far as a single GPU can take it */
+};
 /* ctxs[i] renders rank i of n_ranks; the assembled frame lands in ctxs[root] (pt_framebuffer_read*). Either every rank has its own
- * context on its own device, or all ranks share one context. */
+ * context on its own device, or all ranks share one context, or (PT_COMM_COPY_EXCHANGE) every rank has its own context anywhere. */
 pt_status pt_comm_create(pt_context *const *ctxs, uint32_t n_ranks, uint32_t root, uint32_t flags, pt_comm **out);
 void pt_comm_destroy(pt_comm *comm); /* before or after its contexts: every pt_comm call returns with nothing in flight */
 /* One frame: rank i renders its tiles of `params` (rank / nranks are filled in) on scenes[i] — the same scene committed on every

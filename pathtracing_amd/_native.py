@@ -38,7 +38,7 @@ PT_FLAG_SPLIT_KERNELS = 64
 PT_FLAG_EXTEND_POOL = 128
 PT_SCENE_CORNELL, PT_SCENE_CORNELL_GLASS, PT_SCENE_TRIANGLE_SOUP, PT_SCENE_CORNELL_TESS = 0, 1, 2, 3
 PT_BVH_WIDTH_2, PT_BVH_WIDTH_4, PT_BVH_WIDTH_4Q, PT_BVH_WIDTH_8Q, PT_BVH_WIDTH_8O, PT_BVH_BUILD_LBVH = 2, 4, 68, 72, 73, 0x100
-PT_COMM_FORCE_RCCL = 1
+PT_COMM_FORCE_RCCL, PT_COMM_COPY_EXCHANGE = 1, 2
 
 
 class pt_device_desc(C.Structure):

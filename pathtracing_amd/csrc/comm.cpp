@@ -123,8 +123,12 @@ pt_status pt_comm_create(pt_context *const *ctxs, uint32_t n_ranks, uint32_t roo
             if (ctxs[i] != ctxs[j]) all_same = false;
             if (ctxs[i] == ctxs[j] || context_device(ctxs[i]) == context_device(ctxs[j])) all_distinct = false;
         }
-    if (n_ranks > 1 && !all_same && !all_distinct)
-        return cfail(nullptr, PT_ERR_UNSUPPORTED, "pt_comm_create: ranks must either all have their own context on their own device or all share one context");
+    bool ctx_distinct = true; // every rank its own context (devices may repeat)
+    for (uint32_t i = 0; i < n_ranks; ++i) for (uint32_t j = i + 1; j < n_ranks; ++j) if (ctxs[i] == ctxs[j]) ctx_distinct = false;
+    const bool copies = (flags & PT_COMM_COPY_EXCHANGE) != 0;
+    if (n_ranks > 1 && !all_same && !all_distinct && !(copies && ctx_distinct))
+        return cfail(nullptr, PT_ERR_UNSUPPORTED, "pt_comm_create: ranks must either all have their own context on their own device, or all share one context, "
+                                                  "or (PT_COMM_COPY_EXCHANGE) all have their own context on any devices");
     pt_comm *c = new (std::nothrow) pt_comm();
     if (!c) return cfail(nullptr, PT_ERR_OUT_OF_MEMORY, "host allocation failed");
     c->ctx.assign(ctxs, ctxs + n_ranks);
@@ -132,7 +136,7 @@ pt_status pt_comm_create(pt_context *const *ctxs, uint32_t n_ranks, uint32_t roo
     c->root = root;
     c->shared = n_ranks > 1 && all_same;
     c->staged.assign(n_ranks, 0);
-    c->use_rccl = !c->shared && (n_ranks > 1 || (flags & PT_COMM_FORCE_RCCL));
+    c->use_rccl = !c->shared && !copies && (n_ranks > 1 || (flags & PT_COMM_FORCE_RCCL));
     if (c->use_rccl) {
         if (!g_rccl.load()) { const std::string e = g_rccl.error; delete c; return cfail(nullptr, PT_ERR_UNSUPPORTED, "%s", e.c_str()); }
         std::vector<int> devs(n_ranks);
@@ -222,9 +226,18 @@ pt_status pt_comm_assemble(pt_comm *c, const pt_render_params *p)
                 for (uint32_t i = 0; i < n_posted; ++i) { (void)hipSetDevice(context_device(c->ctx[i])); (void)hipStreamSynchronize(context_stream(c->ctx[i])); }
                 return cfail(c, posted != PT_OK ? posted : PT_ERR_HIP, "%s", msg.c_str());
             }
-        } else { // a single rank without RCCL: its block is the whole gather
-            C_HIP(c, hipSetDevice(context_device(root)));
-            C_HIP(c, hipMemcpyAsync(c->gathered, tiles[0], per_rank * sizeof(float), hipMemcpyDeviceToDevice, context_stream(root)));
+        } else { // without RCCL (a single rank, or PT_COMM_COPY_EXCHANGE): every rank's block is copied to the root's buffer on that rank's own
+                 // stream — after its kernels by stream order; a peer copy over xGMI when the rank lives on another device — then waited for
+            const int rdev = context_device(root);
+            for (uint32_t i = 0; i < n; ++i) {
+                const int dev = context_device(c->ctx[i]);
+                C_HIP(c, hipSetDevice(dev));
+                float *dst = c->gathered + (size_t)per_rank * i;
+                if (dev == rdev) C_HIP(c, hipMemcpyAsync(dst, tiles[i], per_rank * sizeof(float), hipMemcpyDeviceToDevice, context_stream(c->ctx[i])));
+                else C_HIP(c, hipMemcpyPeerAsync(dst, rdev, tiles[i], dev, per_rank * sizeof(float), context_stream(c->ctx[i])));
+            }
+            for (uint32_t i = 0; i < n; ++i)
+                if (c->ctx[i] != root) { C_HIP(c, hipSetDevice(context_device(c->ctx[i]))); C_HIP(c, hipStreamSynchronize(context_stream(c->ctx[i]))); }
         }
     }
     // un-tile on the root: same stream as the root's receive, then the host waits (pt_assemble_tiles is synchronous)

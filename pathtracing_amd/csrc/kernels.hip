@@ -439,7 +439,11 @@ PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FramePar
     // The slot's radiance sum | path count comes from HBM: it is requested up front, whether or not this vertex will touch it, so that
     // its latency runs under the hit-record and material loads below instead of behind them (Cornell 7.04 -> 6.83 ms, Cornell + glass
     // + metal 31.9 -> 31.7, soup 68.2 -> 67.6, 1M-triangle Cornell +-0); written back only if touched.
+#ifdef PT_EXP_NOACC // timing probe only (wrong pictures): what the radiance-sum load costs where it stands
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
     float4 A = at(ps.acc, slot);
+#endif
     bool touched = false, term = false, alive = false;
     auto add = [&](V3 L) {
         touched = true;

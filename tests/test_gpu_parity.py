@@ -3,10 +3,14 @@
 Bars: reference-sphere mode — float within 1e-6 (SURVEY §8c tolerance), RGBA8 within 1 LSB;
 path tracer — ray count identical, image RMSE <= 1e-4 (north_star) — in practice bit-identical.
 """
+import os
+
 import numpy as np
 import pytest
 
 from test_oracle_reference_kat import check_against_kat
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 pytestmark = pytest.mark.gpu
 RMSE_TOL = 1e-4  # BASELINE.json north_star: "images within 1e-4 RMSE of the CPU reference"
@@ -62,7 +66,7 @@ def test_reference_sphere_ragged_sizes(P, pto, renderer, w, h):
     assert np.array_equal(renderer.ReadFramebuffer(), of) and np.array_equal(renderer.ReadFramebufferRGBA8(), ob)
 
 
-@pytest.mark.parametrize("width", [2, 4, 68, 72])
+@pytest.mark.parametrize("width", [2, 4, 68, 72, 73])
 def test_c1_cornell(P, pto, renderer, width):
     """BASELINE config C1: Cornell box, 4 Lambert spheres + area light, 256x256, 4 spp."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL, 0, 0x5EED0001, 256, 256)
@@ -71,14 +75,14 @@ def test_c1_cornell(P, pto, renderer, width):
     assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests)
 
 
-@pytest.mark.parametrize("width", [2, 4, 68, 72])
+@pytest.mark.parametrize("width", [2, 4, 68, 72, 73])
 def test_c4_glass_metal_depth16(P, pto, renderer, width):
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, 200, 150)
     img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(200, 150, spp=8, max_depth=16), width)
     assert_parity(img, st, ref, ost)
 
 
-@pytest.mark.parametrize("width", [2, 4, 68, 72])
+@pytest.mark.parametrize("width", [2, 4, 68, 72, 73])
 def test_c3_triangle_soup(P, pto, renderer, width):
     sd = P.make_scene(P.native.PT_SCENE_TRIANGLE_SOUP, 50000, 0x5EED0001, 160, 120)
     img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(160, 120, spp=4, max_depth=8), width, count=True)
@@ -102,7 +106,7 @@ def test_pool_extend_kernel_is_identical(P, pto, renderer):
     """PT_FLAG_EXTEND_POOL (a wavefront owns 128 queue entries, refills idle lanes while it traverses, shades the pool at full
     width) must not change a single bit nor a single visit count — on every node layout, with holes, streams and deep paths."""
     N = P.native
-    for width in (2, 4, 68, 72):
+    for width in (2, 4, 68, 72, 73):
         sd = P.make_scene(N.PT_SCENE_TRIANGLE_SOUP, 30000, 3, 200, 150)
         p = P.make_params(200, 150, spp=5, max_depth=8, streams=3, flags=N.PT_FLAG_EXTEND_POOL)
         img, st, ref, ost = run_both(P, pto, renderer, sd, p, width, count=True)
@@ -183,6 +187,66 @@ def test_c2_and_c3_as_benchmarked(P, pto, renderer):
     assert kernels in ([1, 2, 2, 2], [1, 1, 2, 2]), kernels
 
 
+def test_c3_and_c4_at_their_exact_sizes(P, pto, renderer):
+    """BASELINE configs[2] and configs[3] exactly as bench.py times them: the 1M-triangle soup at 1920x1080 / 64 spp, and Cornell +
+    glass + rough metal at 1920x1080 / 256 spp / max depth 16, 8 sample streams, default layouts, probed extend kernels — frames
+    bit-identical to the oracle at the same spp and seed, ray counts equal (about a minute of oracle time on the box's host cores)."""
+    sd = P.make_scene(P.native.PT_SCENE_TRIANGLE_SOUP, 1 << 20, 0x5EED0001, 1920, 1080)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(1920, 1080, spp=64, max_depth=8, streams=8), 0)
+    assert renderer.BvhInfo().width == 68
+    assert_parity(img, st, ref, ost)
+    assert st.paths == 1920 * 1080 * 64
+    st2 = renderer.Render(0.0)  # the kernel the probe picked (lane-packing) for the whole frame
+    assert int(st2.reserved[0]) == 2 and st2.rays == ost.rays and np.array_equal(renderer.ReadFramebuffer(), ref)
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, 1920, 1080)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(1920, 1080, spp=256, max_depth=16, streams=8), 0)
+    assert renderer.BvhInfo().width == 2
+    assert_parity(img, st, ref, ost)
+    assert st.paths == 1920 * 1080 * 256
+
+
+def _read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline() == b"PF\n"
+        w, h = (int(v) for v in f.readline().split())
+        assert float(f.readline()) < 0  # little endian
+        return np.frombuffer(f.read(), "<f4").reshape(h, w, 3)[::-1]  # rows are stored bottom-up
+
+
+def test_native_host_cli(P, pto, renderer, tmp_path):
+    """The compiled host over the C ABI (host/cpp/ptrt_cli: the stand-in for Program.cs:1-9 / App.cs:15-50 that this image can
+    build) run as a program: one device, and three ranks through pt_comm on one device (--gpus 3 --virtual 1). Its PFM output must
+    be the oracle's frame byte for byte, its PPM the UNORM8 image; the reference scene must be the reference's image."""
+    import subprocess
+    cli = os.path.join(os.path.dirname(HERE), "host", "cpp", "ptrt_cli")
+    assert os.path.exists(cli), "host/cpp/ptrt_cli is built by __graft_entry__.build()"
+    w, h, spp = 200, 131, 3
+    sd = P.make_scene(P.native.PT_SCENE_CORNELL_GLASS, 0, 0x5EED0001, w, h)
+    _, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(w, h, spp=spp, max_depth=8, streams=8), 0)  # the CLI's defaults
+    want8 = renderer.ReadFramebufferRGBA8()
+    for extra in ([], ["--gpus", "3", "--virtual", "1"], ["--gpus", "2", "--virtual", "2"]):
+        pfm, ppm = str(tmp_path / "f.pfm"), str(tmp_path / "f.ppm")
+        out = subprocess.run([cli, "--scene", "glass", "--size", f"{w}x{h}", "--spp", str(spp), "--pfm", pfm, "--ppm", ppm] + extra,
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.startswith(f"{ost.rays} rays"), (out.stdout, ost.rays, extra)
+        got = _read_pfm(pfm)
+        assert got.shape == (h, w, 3) and np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref[..., :3]).view(np.uint32)), extra
+        with open(ppm, "rb") as f:
+            assert f.readline() == b"P6\n" and f.readline().split() == [str(w).encode(), str(h).encode()] and f.readline() == b"255\n"
+            assert np.array_equal(np.frombuffer(f.read(), np.uint8).reshape(h, w, 3), want8[..., :3])
+    ppm = str(tmp_path / "ref.ppm")
+    out = subprocess.run([cli, "--scene", "reference", "--size", "320x200", "--ppm", ppm], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    _, b = pto.reference_sphere(320, 200)
+    with open(ppm, "rb") as f:
+        for _ in range(3):
+            f.readline()
+        assert np.array_equal(np.frombuffer(f.read(), np.uint8).reshape(200, 320, 3), b[..., :3])
+    bad = subprocess.run([cli, "--scene", "glass", "--size", "0x0"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "ptrt status" in bad.stderr  # every failure is an exception, as in the reference (Renderer.cs:1022-1025)
+
+
 def test_largest_slot_space(P, pto, renderer):
     """The largest frame the kernels' 32-bit slot offsets allow (2^28 slots = pixels x streams): 3840x2160 with 32 sample streams is
     265 M slots (a 4.2 GB float4 array: byte offsets just below 2^32). One sample per stream, depth 4, against the oracle; one stream
@@ -217,7 +281,7 @@ def test_4k_frame_and_full_hd_soup(P, pto, renderer):
     assert_parity(img, st, ref, ost)
 
 
-@pytest.mark.parametrize("layout", [2, 4, 68, 72])
+@pytest.mark.parametrize("layout", [2, 4, 68, 72, 73])
 def test_gpu_lbvh_builder(P, pto, renderer, layout):
     """hierarchy built on the GPU (Morton sort + Karras + refit). The blob must pass the oracle's structural
     validator, the HIP frame must equal the oracle traversing THOSE bytes (rays and visit counts included), and — because the
@@ -292,6 +356,40 @@ def test_comm_rccl_path_on_one_gpu(P, pto, renderer):
             assert stats[0].rays == one.rays and np.array_equal(renderer.ReadFramebuffer(), want)
     with pytest.raises(P.PtException):
         P.Comm([renderer], root=1)
+
+
+def test_comm_with_a_context_per_rank_on_one_gpu(P, pto, renderer):
+    """pt_comm's multi-context branch as far as one GPU can take it (PT_COMM_COPY_EXCHANGE): three ranks, each with its OWN context
+    (own streams, queues, tile buffer) on device 0, rendered concurrently by one host thread per context inside pt_comm_render; the
+    tile blocks reach the root by device copies on the ranks' own streams; un-tiled on the root. Frame = the single-context frame bit
+    for bit, also with the root in the middle, also when the comm outlives nothing and is destroyed after its contexts."""
+    N = P.native
+    w, h = 333, 190
+    sd = P.make_scene(N.PT_SCENE_CORNELL_TESS, 20000, 3, w, h)
+    p = P.make_params(w, h, spp=5, max_depth=6, streams=2)
+    renderer.SetScene(sd, 0)
+    renderer.Params = p
+    one = renderer.Render(0.0)
+    want = renderer.ReadFramebuffer()
+    rs = [P.Renderer(P.Window(w, h)) for _ in range(3)]
+    try:
+        for r in rs:
+            r.Init()
+            r.SetScene(sd, 0)
+        with pytest.raises(P.PtException):  # without the flag distinct contexts on one device are refused (they would need RCCL ranks on one GPU)
+            P.Comm(rs)
+        for root in (0, 1):
+            with P.Comm(rs, root=root, flags=N.PT_COMM_COPY_EXCHANGE) as comm:
+                for _ in range(2):
+                    stats = comm.Render(p)
+                    assert sum(s.rays for s in stats) == one.rays
+                    assert np.array_equal(rs[root].ReadFramebuffer(), want), root
+        comm = P.Comm(rs, flags=N.PT_COMM_COPY_EXCHANGE)
+        comm.Render(p)
+    finally:
+        for r in rs:
+            r.Dispose()
+    comm.Dispose()  # after its contexts: pt_comm_destroy does not touch them
 
 
 def test_rccl_gather_aliases_the_tile_buffer(P, pto, renderer):
@@ -406,7 +504,7 @@ def test_edge_cases(P, pto, renderer):
     sd = P.SceneData(cam=cam)
     sd.verts = np.array([[-1, -1, 0, 1, -1, 0, 0, 1, 0]], np.float32); sd.tri_mat = np.zeros(1, np.uint32)
     m = np.zeros(1, P.MATERIAL_DTYPE); m["albedo"] = 0.5; m["emission"] = (1, 2, 3); sd.mats = m
-    for width in (2, 4, 68, 72):
+    for width in (2, 4, 68, 72, 73):
         img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(70, 40, spp=1, max_depth=1), width)
         assert_parity(img, st, ref, ost)
         assert st.rays == 70 * 40 and img[..., 0].max() == 1.0
@@ -599,7 +697,7 @@ def test_randomised_configurations_against_the_oracle(P, pto, renderer):
             if case % 9 == 8:
                 spp = int(rng.integers(34, 48))  # many samples per stream: the predicted-ratio rule, not the sticky one
             streams = int(rng.choice([0, 1, 2, 3, 8, 16]))
-            width = int(rng.choice([0, 2, 4, 68, 72]))
+            width = int(rng.choice([0, 2, 4, 68, 72, 73]))
             flags = int(rng.choice([0, 0, N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_EXTEND_SIMPLE, N.PT_FLAG_EXTEND_POOL, N.PT_FLAG_EXTEND_POOL,
                                     N.PT_FLAG_SPLIT_KERNELS, N.PT_FLAG_SPLIT_KERNELS | N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_BUCKET_SPECULAR]))
             offset = int(rng.integers(0, 5))
