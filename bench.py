@@ -98,6 +98,7 @@ def main():
     torch.cuda.set_device(device)
     exchange = world > 1 or args.force_exchange
     if exchange:
+        # (RCCL prints its version banner on stdout under the GPU boxes' NCCL_DEBUG=VERSION; the JSON line is the LAST line of stdout)
         if args.rehearse_gloo:
             dist.init_process_group("gloo")
         elif world > 1:

@@ -328,11 +328,22 @@ PT_DEV void cswap(uint32_t (&key)[N], int32_t (&ref)[N], int a, int b)
         const int32_t tr = ref[a]; ref[a] = ref[b]; ref[b] = tr;
     }
 }
+// Two independent compare-exchanges with both comparisons issued before the first select: a v_cmp that writes an SGPR pair must be two
+// instructions ahead of the v_cndmask that reads it (gfx950 hazard: the compiler otherwise pads every comparator with `s_nop 1`).
+template <int N>
+PT_DEV void cswap2(uint32_t (&key)[N], int32_t (&ref)[N], int a, int b, int c, int d)
+{
+    const bool s0 = key[a] > key[b], s1 = key[c] > key[d];
+    const uint32_t ka = key[a], kb = key[b], kc = key[c], kd = key[d];
+    const int32_t ra = ref[a], rb = ref[b], rc = ref[c], rd = ref[d];
+    key[a] = s0 ? kb : ka; key[b] = s0 ? ka : kb; ref[a] = s0 ? rb : ra; ref[b] = s0 ? ra : rb;
+    key[c] = s1 ? kd : kc; key[d] = s1 ? kc : kd; ref[c] = s1 ? rd : rc; ref[d] = s1 ? rc : rd;
+}
 template <int N>
 PT_DEV void sort_head(uint32_t (&key)[N], int32_t (&ref)[N])
 {
     if constexpr (N == 2) { cswap(key, ref, 0, 1); }
-    else if constexpr (N == 4) { cswap(key, ref, 0, 1); cswap(key, ref, 2, 3); cswap(key, ref, 0, 2); }
+    else if constexpr (N == 4) { cswap2(key, ref, 0, 1, 2, 3); cswap2(key, ref, 0, 2, 1, 3); }
     else { // 19-comparator network for 8 keys, whole
         cswap(key, ref, 0, 1); cswap(key, ref, 2, 3); cswap(key, ref, 4, 5); cswap(key, ref, 6, 7); cswap(key, ref, 0, 2); cswap(key, ref, 1, 3);
         cswap(key, ref, 4, 6); cswap(key, ref, 5, 7); cswap(key, ref, 1, 2); cswap(key, ref, 5, 6); cswap(key, ref, 0, 4); cswap(key, ref, 3, 7);
@@ -343,7 +354,7 @@ PT_DEV void sort_head(uint32_t (&key)[N], int32_t (&ref)[N])
 template <int N>
 PT_DEV void sort_tail(uint32_t (&key)[N], int32_t (&ref)[N])
 {
-    if constexpr (N == 4) { cswap(key, ref, 1, 3); cswap(key, ref, 1, 2); }
+    if constexpr (N == 4) { cswap(key, ref, 1, 2); } // (0,1)(2,3) | (0,2)(1,3) | (1,2): the five comparators, in three rounds
 }
 template <int L>
 PT_DEV void visit_node(const float4 *__restrict__ nd, float4 r0, float4 r1, float4 r2, float4 r3, const RaySetup &rs, float t_best,

@@ -442,6 +442,8 @@ def test_bench_exchange_path_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    rk = line["ranks"]  # what every rank did: wall time, rays, kernel time per frame; rays add up to the frame
+    assert len(rk["wall_s"]) == 2 and sum(rk["rays_per_frame"]) == line["config"]["rays_per_frame"] and rk["gpu_ms_max_over_mean"] >= 1.0
 
 
 @pytest.mark.parametrize("streams", [2, 4, 7, 40])
