@@ -682,6 +682,82 @@ def test_app_runs_the_reference_frame(P, pto):
     assert b.shape == (1080, 1920, 4) and int((b[..., 2] > 0).sum()) == 305317
 
 
+def test_host_readback_and_kernel_pin(P, pto):
+    """pt_tuning.readback / lag / extend_kernel (ABI 2). How a launch's queue sizes reach the host — stored to mapped pinned memory by
+    the next launch's first threads (default) or copied behind every launch — and how far the host runs ahead are scheduling only:
+    same frame, same rays, for every combination, on long frames and on frames that are over within the run-ahead. A pinned extend
+    kernel is the one that runs (pt_stats.reserved[0]) unless a frame's flag overrides it; out-of-range values are refused."""
+    N = P.native
+    sd = P.make_scene(N.PT_SCENE_CORNELL_TESS, 6000, 9, 260, 150)
+    r = P.Renderer(P.Window(260, 150)); r.Init()
+    try:
+        r.SetScene(sd, 0)
+        info = r.BvhInfo()
+        osc = pto.Scene(sd, (info.width,) + r.BvhRead())
+        for spp, depth in ((1, 2), (9, 8), (40, 6)):
+            p = P.make_params(260, 150, spp=spp, max_depth=depth, streams=4)
+            ref, ost = pto.render(osc, p)
+            for readback in (0, 1):
+                for lag in (0, 2, 3, 5):
+                    for loops in (1, 2):
+                        r.SetTuning(readback=readback, lag=lag, loops=loops, extend_kernel=1)
+                        r.Params = p
+                        for _ in range(2):  # twice: the second frame starts from the cached queue / counter template
+                            st = r.Render(0.0)
+                            assert st.rays == ost.rays and np.array_equal(r.ReadFramebuffer(), ref), (spp, readback, lag, loops)
+        p = P.make_params(260, 150, spp=9, max_depth=8, streams=4)
+        for pin in (1, 2, 3):
+            r.SetTuning(readback=0, lag=0, loops=0, extend_kernel=pin)
+            r.Params = p
+            assert int(r.Render(0.0).reserved[0]) == pin
+        r.Params = P.make_params(260, 150, spp=9, max_depth=8, streams=4, flags=N.PT_FLAG_EXTEND_SIMPLE)
+        assert int(r.Render(0.0).reserved[0]) == 1  # a frame's flag beats the context's pin
+        for bad in (dict(extend_kernel=4), dict(readback=2), dict(lag=1), dict(lag=6)):
+            with pytest.raises(P.PtException):
+                r.SetTuning(**bad)
+        # frames too small to time settle on the one-ray-per-lane kernel instead of probing for ever (one loop, no finish mode)
+        r.SetTuning(extend_kernel=0)
+        r.SetScene(sd, 0)
+        r.Params = P.make_params(64, 64, spp=2, max_depth=4, streams=2)
+        seen = [int(r.Render(0.0).reserved[0]) for _ in range(6)]
+        assert seen[-1] == 1 and seen[-2] == 1
+    finally:
+        r.Dispose()
+
+
+def test_frame_start_template_follows_the_geometry(P, pto, renderer):
+    """The first queue and counter block of a frame are cached per frame geometry (api.cpp: q_init / cnt_init). Changing size, rank
+    split, stream count, a sample count below the stream count, or the sample offset must rebuild them: every frame of the
+    sequence — including returns to an earlier geometry and progressive frames that continue one — equals the oracle's."""
+    N = P.native
+    sd = P.make_scene(N.PT_SCENE_CORNELL_GLASS, 0, 12, 200, 120)
+    renderer.SetScene(sd, 0)
+    info = renderer.BvhInfo()
+    osc = pto.Scene(sd, (info.width,) + renderer.BvhRead())
+    seq = [(200, 120, 6, 4, 0), (200, 120, 6, 4, 0), (130, 97, 6, 4, 0), (130, 97, 2, 4, 0), (130, 97, 2, 4, 3), (130, 97, 6, 8, 0),
+           (200, 120, 6, 4, 0), (64, 64, 1, 1, 0), (200, 120, 3, 4, 1)]
+    for w, h, spp, streams, offset in seq:
+        sdw = P.make_scene(N.PT_SCENE_CORNELL_GLASS, 0, 12, w, h)  # the camera follows the aspect ratio
+        renderer.SetScene(sdw, 0)
+        p = P.make_params(w, h, spp=spp, max_depth=7, streams=streams, sample_offset=offset)
+        renderer.Params = p
+        st = renderer.Render(0.0)
+        ref, ost = pto.render(pto.Scene(sdw, (renderer.BvhInfo().width,) + renderer.BvhRead()), p)
+        assert st.rays == ost.rays and np.array_equal(renderer.ReadFramebuffer(), ref), (w, h, spp, streams, offset)
+    # progressive: 3 + 2 + 4 samples continue one set of partial sums across the cached frame start (the stream phase changes each time)
+    sdw = P.make_scene(N.PT_SCENE_CORNELL_GLASS, 0, 12, 200, 120)
+    renderer.SetScene(sdw, 0)
+    whole = P.make_params(200, 120, spp=9, max_depth=7, streams=4)
+    ref, _ = pto.render(pto.Scene(sdw, (renderer.BvhInfo().width,) + renderer.BvhRead()), whole)
+    done = 0
+    for k, n in enumerate((3, 2, 4)):
+        renderer.Params = P.make_params(200, 120, spp=n, max_depth=7, streams=4, sample_offset=done, flags=N.PT_FLAG_ACCUMULATE if k else 0)
+        renderer.Render(0.0)
+        done += n
+    assert np.array_equal(renderer.ReadFramebuffer(), ref)
+    del osc
+
+
 def test_randomised_configurations_against_the_oracle(P, pto, renderer):
     """A fixed-seed sweep over scene kind, frame size (ragged tiles), spp, depth, streams, node layout, extend kernel, pipeline,
     sample offset and the scheduling knobs (pt_tuning: loops, bounces per launch, re-packing threshold and sticky limit, run-to-end
@@ -705,7 +781,8 @@ def test_randomised_configurations_against_the_oracle(P, pto, renderer):
             offset = int(rng.integers(0, 5))
             tune = dict(loops=int(rng.choice([0, 1, 2, 4])), bounces=int(rng.choice([0, 0, 1, 2, 3, 5, 8])),
                         compact_below=float(rng.choice([0.0, 0.5, 0.9, 0.9, 1.0, 2.0])), sticky_samples=int(rng.choice([0, 2, 32, 32, 1000])),
-                        finish_below=int(rng.choice([0, 64, 4096, 4096, 1 << 20])), lag=int(rng.choice([0, 0, 2, 3, 4])))
+                        finish_below=int(rng.choice([0, 64, 4096, 4096, 1 << 20])), lag=int(rng.choice([0, 0, 2, 3, 4, 5])),
+                        readback=int(rng.choice([0, 0, 1])), extend_kernel=int(rng.choice([0, 0, 0, 1, 2, 3])))
             renderer.SetTuning(**tune)
             sd = P.make_scene(kind, detail, int(rng.integers(1, 1 << 30)), w, h)
             p = P.make_params(w, h, spp=spp, max_depth=depth, streams=streams, flags=flags, sample_offset=offset, seed=int(rng.integers(1 << 31)))
@@ -717,7 +794,7 @@ def test_randomised_configurations_against_the_oracle(P, pto, renderer):
             if count:
                 assert (st.node_visits, st.tri_tests, st.sphere_tests) == (ost.node_visits, ost.tri_tests, ost.sphere_tests), ctx
     finally:
-        renderer.SetTuning(**{k: getattr(defaults, k) for k in ("bounces", "loops", "finish_below", "packed_chunk", "compact_below", "sparse_below", "sticky_samples", "lag")})
+        renderer.SetTuning(**{k: getattr(defaults, k) for k, _ in defaults._fields_})
 
 
 @pytest.mark.gpu

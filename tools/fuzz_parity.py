@@ -26,7 +26,7 @@ for case in range(cases):
     if case % 7 == 6:
         spp = int(rng.integers(34, 80))
     streams = int(rng.choice([0, 1, 2, 3, 8, 16]))
-    width = int(rng.choice([0, 2, 4, 68, 72]))
+    width = int(rng.choice([0, 2, 4, 68, 72, 73]))
     flags = int(rng.choice([0, 0, 0, N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_EXTEND_SIMPLE, N.PT_FLAG_EXTEND_POOL, N.PT_FLAG_SPLIT_KERNELS,
                             N.PT_FLAG_SPLIT_KERNELS | N.PT_FLAG_EXTEND_PACKED, N.PT_FLAG_BUCKET_SPECULAR]))
     if rng.integers(4) == 0 and width in (0, 68):
@@ -34,7 +34,8 @@ for case in range(cases):
     nranks = int(rng.choice([1, 1, 1, 2, 3, 8]))  # > 1: virtual ranks on this GPU through pt_comm
     tune = dict(loops=int(rng.choice([0, 1, 2, 4])), bounces=int(rng.choice([0, 0, 1, 2, 3, 5, 8])),
                 compact_below=float(rng.choice([0.0, 0.5, 0.9, 0.9, 1.0, 2.0])), sticky_samples=int(rng.choice([0, 2, 32, 32, 1000])),
-                finish_below=int(rng.choice([0, 64, 4096, 4096, 1 << 20])), lag=int(rng.choice([0, 0, 2, 3, 4])))
+                finish_below=int(rng.choice([0, 64, 4096, 4096, 1 << 20])), lag=int(rng.choice([0, 0, 2, 3, 4, 5])),
+                readback=int(rng.choice([0, 0, 1])), extend_kernel=int(rng.choice([0, 0, 0, 1, 2, 3])))
     r.SetTuning(**tune)
     sd = P.make_scene(kind, detail, int(rng.integers(1, 1 << 30)), w, h)
     p = P.make_params(w, h, spp=spp, max_depth=depth, streams=streams, flags=flags, sample_offset=int(rng.integers(0, 5)), seed=int(rng.integers(1 << 31)))
