@@ -74,6 +74,7 @@ struct pt_context {
     struct InitKey { uint32_t w, h, rank, nranks, streams, first_spp, offset, n_slots, shard_cap; const void *q, *acc;
                      bool operator==(const InitKey &o) const { return std::memcmp(this, &o, sizeof *this) == 0; } } init_key{};
     bool init_valid = false;
+    uint32_t init_bound = 0; // longest shard queue of the template: the first launch's grid bound
     uint32_t *h_counts = nullptr; // pinned: kLag readbacks of the per-shard queue sizes (pt_tuning.readback = 1) + one copy of all counters
     uint4 *h_ring = nullptr, *d_ring = nullptr; // mapped pinned memory the extend kernels report their queue sizes to, kLag x kShards lines
                                                 // (host address, device address); PathState::host_ring
@@ -687,7 +688,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     if (full_state) {
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * kCntTotalWords, q));
         HIP_TRY(c, hipEventRecord(c->ev_start, q));
-        HIP_TRY(c, launch_generate(q, sc, ps, fp, true));
+        HIP_TRY(c, launch_generate(q, sc, ps, fp, 1u));
     } else {
         // k_generate's output depends on the frame's geometry only (which slots exist: size, rank, streams, whether every stream has
         // a sample): made once per geometry, then a frame starts with a copy of the counter block (pt_context::q_init)
@@ -701,7 +702,16 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
             HIP_TRY(c, hipMemsetAsync(c->cnt_init.p, 0, sizeof(uint32_t) * kCntTotalWords, q));
             PathState pt = ps;
             pt.counters = c->cnt_init.p; pt.q_ext[0] = c->q_init.p;
-            HIP_TRY(c, launch_generate(q, sc, pt, fp, false)); // also zeroes every slot's sum (slots that never hold a path stay zero from here on)
+            // whole streams without a sample (spp < streams): the first queue holds the live slots only, and the first launch is sized by it
+            const bool dense = key.first_spp < streams;
+            HIP_TRY(c, launch_generate(q, sc, pt, fp, dense ? 2u : 0u)); // also zeroes every slot's sum (slots that never hold a path stay zero from here on)
+            c->init_bound = shard_cap;
+            if (dense) {
+                HIP_TRY(c, hipMemcpyAsync(c->h_counts + kFinalOffset, c->cnt_init.p, sizeof(uint32_t) * kShards * kCounterStride, hipMemcpyDeviceToHost, q));
+                HIP_TRY(c, hipStreamSynchronize(q));
+                c->init_bound = 0;
+                for (uint32_t sh = 0; sh < kShards; ++sh) c->init_bound = std::max(c->init_bound, c->h_counts[kFinalOffset + cnt_ext_index(0, sh)]);
+            }
             c->init_key = key; c->init_valid = true;
         }
         HIP_TRY(c, hipEventRecord(c->ev_start, q));
@@ -738,7 +748,7 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     Loop loops[kMaxGroups];
     HIP_TRY(c, hipEventRecord(c->ev_fork, q));
     for (uint32_t g = 0; g < n_loops; ++g) {
-        loops[g] = Loop{ n_loops == 1 ? q : c->group_stream[g], g * per_group, shard_cap, 0u, false }; // no shard's queue can outgrow its slots
+        loops[g] = Loop{ n_loops == 1 ? q : c->group_stream[g], g * per_group, full_state ? shard_cap : c->init_bound, 0u, false }; // no shard's queue can outgrow its first one
         if (loops[g].stream != q) HIP_TRY(c, hipStreamWaitEvent(loops[g].stream, c->ev_fork, 0));
     }
     const uint64_t max_iters = (uint64_t)p->spp * p->max_depth + kLag + 2;

@@ -410,13 +410,22 @@ PT_DEV void path_init(const DeviceScene &sc, const FrameParams &fp, uint32_t slo
 }
 
 // ------------------------------------------------------------------------------------------------
-// grid (ceil(shard_cap/256), kShards): entry j of shard s is slot ((j>>G)*kShards + s)*2^G + (j & (2^G - 1)), G = kShardGroupShift
+// grid (ceil(shard_cap/256), kShards). Which slots a shard owns is decided here and nowhere else (queues only ever hand a slot on to
+// the same shard): entry group t = j >> G of shard s is slot group t * kShards + (s - t) mod kShards, G = kShardGroupShift. Every run of
+// kShards consecutive slot groups — with 8 streams: the 8 streams of 8 neighbouring pixel blocks — is dealt over all shards, and the deal
+// ROTATES by one shard from run to run: the groups of one sample stream would otherwise all land on the shards s with s % streams ==
+// stream, i.e. (a shard's workgroups staying on one XCD) on one XCD — a frame with fewer samples than streams (one progressive sample
+// per call) then ran on an eighth of the chip (1080p, 1 spp, 8 streams: 1.45 -> 0.5 ms).
 __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState ps, FrameParams fp, uint32_t full)
 {
     uint32_t shard, bx, nbx;
     block_pos(ps, shard, bx, nbx);
     const uint32_t j = bx * kBlock + threadIdx.x;
-    const uint32_t slot = (((j >> kShardGroupShift) * kShards + shard) << kShardGroupShift) | (j & ((1u << kShardGroupShift) - 1u));
+#ifndef PT_DEAL_ROT
+#define PT_DEAL_ROT 1
+#endif
+    const uint32_t t = j >> kShardGroupShift, rot = (shard + kShards - (t * PT_DEAL_ROT) % kShards) % kShards;
+    const uint32_t slot = ((t * kShards + rot) << kShardGroupShift) | (j & ((1u << kShardGroupShift) - 1u));
     uint32_t x = 0, y = 0;
     const bool in_range = j < ps.shard_cap && slot < ps.n_slots;
     // stream k takes the samples s with (sample_offset + s) % K == k, in increasing s (docs/SPEC.md §5)
@@ -425,17 +434,20 @@ __global__ void __launch_bounds__(kBlock) k_generate(DeviceScene sc, PathState p
     if (in_range && !fp.accumulate) ps.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     // `full` == 0: the first launch of a fused extend kernel builds the state of its slots in registers (path_init) instead of
     // reading it back: 52 bytes per slot not written here and not read there
-    if (valid && full) {
+    if (valid && full == 1u) {
         PathRegs r;
         path_init(sc, fp, slot, r);
         path_store(ps, slot, r);
     }
-    // the first queue is the shard's slots in slot order, holes (off-image pixels, streams with no sample) included
-    if (j < ps.shard_cap) ps.q_ext[0][(size_t)shard * ps.shard_cap + j] = valid ? slot : kInvalidSlot;
+    // the first queue is the shard's slots in slot order, holes (off-image pixels, streams with no sample) included — or, full == 2
+    // (frames in which whole streams have no sample: spp < streams, e.g. one progressive sample per call), only the slots that
+    // hold a path, appended per wavefront: the first launch then covers spp/streams of the slots instead of all of them
+    if (full == 2u) wave_push(&ps.counters[cnt_ext_index(0, shard)], ps.q_ext[0] + (size_t)shard * ps.shard_cap, valid, slot);
+    else if (j < ps.shard_cap) ps.q_ext[0][(size_t)shard * ps.shard_cap + j] = valid ? slot : kInvalidSlot;
     const uint32_t n_alive = (uint32_t)__syncthreads_count(valid);
     if (threadIdx.x == 0) {
         if (n_alive) atomicAdd(&ps.counters[cnt_alive_index(0, shard)], n_alive);
-        if (bx == 0) ps.counters[cnt_ext_index(0, shard)] = ps.shard_cap;
+        if (bx == 0 && full != 2u) ps.counters[cnt_ext_index(0, shard)] = ps.shard_cap;
     }
 }
 
@@ -1426,9 +1438,9 @@ hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4
     return hipGetLastError();
 }
 
-hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, bool full_state)
+hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t mode)
 {
-    hipLaunchKernelGGL(k_generate, shard_grid(blocks_for(ps.shard_cap), ps.shard_count), dim3(kBlock), 0, s, sc, ps, fp, full_state ? 1u : 0u);
+    hipLaunchKernelGGL(k_generate, shard_grid(blocks_for(ps.shard_cap), ps.shard_count), dim3(kBlock), 0, s, sc, ps, fp, mode);
     return hipGetLastError();
 }
 

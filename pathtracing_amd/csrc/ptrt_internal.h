@@ -127,9 +127,10 @@ struct FrameParams {
 // kernel launchers (kernels.hip). All enqueue on `s` and return the launch error.
 // `shard_bound` = upper bound of any shard's queue length for this launch.
 hipError_t launch_reference_sphere(hipStream_t s, uint32_t w, uint32_t h, float4 *out_f, uint32_t *out_rgba8);
-// full_state: write every slot's initial path state (k_shade and k_extend_pool read it back); false when the frame's first launch is a fused
-// one-ray-per-lane or lane-packing kernel, which builds it in registers
-hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, bool full_state);
+// mode 1: write every slot's initial path state (k_shade and k_extend_pool read it back); 0: queue and counters only — the frame's first
+// launch is a fused one-ray-per-lane or lane-packing kernel, which builds the state in registers; 2: like 0 with the queue dense (only
+// slots that hold a path: frames in which whole sample streams are empty)
+hipError_t launch_generate(hipStream_t s, const DeviceScene &sc, const PathState &ps, const FrameParams &fp, uint32_t mode);
 // `it` = iteration index of the wavefront loop: queues alternate by it & 1, queue counters rotate by it % 3.
 // kernel: ExtendKernel. fuse: -1 = extend only (k_shade follows); 0 / 2 = the kernel also shades (Lambert-only / all kinds) and
 // queues the next iteration, honouring `compact` like launch_shade. packed_chunk: queue entries per wavefront of EXT_PACKED.
