@@ -6,7 +6,7 @@ W,H=1920,1080
 r=P.Renderer(P.Window(W,H)); r.Init()
 for scene,kind,detail in (("tess",N.PT_SCENE_CORNELL_TESS,1<<20),("glass",N.PT_SCENE_CORNELL_GLASS,0)):
     r.SetScene(P.make_scene(kind,detail,0x5EED0001,W,H),0)
-    for spp,streams in ((1,1),(2,2),(4,4),(8,8),(8,4),(16,8),(64,8)):
+    for spp,streams in ((1,1),(1,8),(2,8),(2,2),(4,4),(8,8),(8,4),(16,8),(64,8)):
         done=0
         r.Params=P.make_params(W,H,spp=spp,max_depth=8,streams=streams,sample_offset=0); r.Render(0.0); done=spp
         t0=time.perf_counter(); rays=0; gpu=0.0; n=20
