@@ -758,6 +758,26 @@ def test_frame_start_template_follows_the_geometry(P, pto, renderer):
     del osc
 
 
+@pytest.mark.parametrize("kind,depth,spp,n,own_roulette,seed", [(0, 8, 16384, 30000, False, 77), (1, 16, 32768, 40000, True, 4242)])
+def test_hip_frames_match_the_independent_estimator(P, renderer, kind, depth, spp, n, own_roulette, seed):
+    """The physics pin of tests/test_physics_pin.py applied to the HIP path itself, without the oracle in between: converged 4 x 4
+    frames of the Cornell box and of C4's glass + rough-metal scene FROM THE DEVICE against the float64 numpy tracer that shares no
+    sampling routine, RNG, weight formula or intersection code with it — every channel within the same bands (3 sigma, chi-square)."""
+    from test_physics_pin import numpy_radiance
+    w = h = 4
+    sd = P.make_scene(kind, 0, 0x5EED0001, w, h)
+    renderer.SetScene(sd, 0)
+    renderer.Params = P.make_params(w, h, spp=spp, max_depth=depth, rr_start=3, seed=seed, streams=8)
+    renderer.Render(0.0)
+    img = renderer.ReadFramebuffer()
+    mean, err = numpy_radiance(sd, w, h, n, depth, 3, np.random.default_rng(2026 + kind), own_roulette=own_roulette)
+    sigma = np.sqrt(err ** 2 + (err * np.sqrt(n / spp)) ** 2)
+    z = np.abs(img[..., :3] - mean) / np.maximum(sigma, 1e-6)
+    assert (z > 3.0).sum() <= 3 and z.max() < 5.0, (z.max(), (z > 3).sum())
+    assert (z * z).sum() < 48 + 6 * np.sqrt(2 * 48), (z * z).sum()
+    assert img[..., :3].mean() > 0.05 and (img[..., 3] == 1.0).all()
+
+
 def test_randomised_configurations_against_the_oracle(P, pto, renderer):
     """A fixed-seed sweep over scene kind, frame size (ragged tiles), spp, depth, streams, node layout, extend kernel, pipeline,
     sample offset and the scheduling knobs (pt_tuning: loops, bounces per launch, re-packing threshold and sticky limit, run-to-end
