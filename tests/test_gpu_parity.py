@@ -444,6 +444,13 @@ def test_bench_exchange_path_on_one_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     rk = line["ranks"]  # what every rank did: wall time, rays, kernel time per frame; rays add up to the frame
     assert len(rk["wall_s"]) == 2 and sum(rk["rays_per_frame"]) == line["config"]["rays_per_frame"] and rk["gpu_ms_max_over_mean"] >= 1.0
+    # four ranks (with the test's own context: five processes on the card, the most a box allows short of its limit of six): the frame
+    # split four ways, gathered and assembled as the driver's N = 4 run would; bench.py asserts the assembled frame is the one-rank frame
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", "29733",
+                          os.path.join(root, "bench.py"), "--gpus", "4", "--rehearse-gloo"] + common, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and len(line["ranks"]["gpu_ms_per_frame"]) == 4 and sum(line["ranks"]["rays_per_frame"]) == line["config"]["rays_per_frame"]
 
 
 @pytest.mark.parametrize("streams", [2, 4, 7, 40])
