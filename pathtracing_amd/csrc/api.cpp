@@ -226,9 +226,16 @@ pt_status pt_context_create(const pt_device_desc *desc, pt_context **out)
         c->own_stream = true;
     }
     bool ok = hipHostMalloc((void **)&c->h_counts, sizeof(uint32_t) * (kFinalOffset + kCntTotalWords), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&c->h_ring, sizeof(uint4) * kLag * kShards, hipHostMallocMapped) == hipSuccess &&
-         hipHostGetDevicePointer((void **)&c->d_ring, c->h_ring, 0) == hipSuccess;
-    if (ok) std::memset(c->h_ring, 0, sizeof(uint4) * kLag * kShards);
+    if (ok) { // host-mapped ring for the kernels' own size reports; a platform without mapped pinned memory falls back to a copy per launch
+        if (hipHostMalloc((void **)&c->h_ring, sizeof(uint4) * kLag * kShards, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void **)&c->d_ring, c->h_ring, 0) == hipSuccess && c->d_ring)
+            std::memset(c->h_ring, 0, sizeof(uint4) * kLag * kShards);
+        else {
+            if (c->h_ring) (void)hipHostFree(c->h_ring);
+            c->h_ring = c->d_ring = nullptr; c->readback = 1u;
+            (void)hipGetLastError();
+        }
+    }
     for (uint32_t g = 0; ok && g < kMaxGroups; ++g) {
         ok = hipStreamCreateWithFlags(&c->group_stream[g], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) == hipSuccess;
@@ -266,6 +273,7 @@ pt_status pt_context_set_tuning(pt_context *c, const pt_tuning *t)
     c->bounces = t->bounces; c->groups = t->loops; c->finish_below = t->finish_below; c->packed_chunk = t->packed_chunk;
     if (t->extend_kernel > (uint32_t)EXT_POOL) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: extend_kernel must be 0 (probed), 1 (one ray per lane), 2 (lane-packing) or 3 (pooled)");
     if (t->readback > 1) return fail(c, PT_ERR_INVALID_ARGUMENT, "tuning: readback must be 0 (mapped store) or 1 (copy per launch)");
+    if (t->readback == 0 && !c->d_ring) return fail(c, PT_ERR_UNSUPPORTED, "tuning: readback 0 needs host-mapped pinned memory, which this platform did not provide");
     c->compact_below = t->compact_below; c->sparse_below = t->sparse_below; c->sticky_samples = t->sticky_samples; c->lag = t->lag;
     c->extend_kernel = t->extend_kernel; c->readback = t->readback;
     return PT_OK;
