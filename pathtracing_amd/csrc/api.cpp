@@ -675,6 +675,8 @@ static pt_status render_frame(pt_context *c, const pt_scene *s, const pt_render_
     fp.seed_hashed = host_pcg(p->seed); fp.sample_offset = p->sample_offset; fp.ray_eps = p->ray_eps;
     fp.rank = p->rank; fp.nranks = nranks; fp.tiles_x = lay.tiles_x; fp.n_tiles = lay.n_tiles;
     fp.streams = streams; fp.slots_per_stream = pixel_slots;
+    div_magic(streams, fp.streams_magic, fp.streams_shift); div_magic(lay.tiles_x, fp.tiles_x_magic, fp.tiles_x_shift);
+    fp.offset_mod = p->sample_offset % streams;
     // progressive accumulation (the reference re-renders every frame, App.cs:39-42; this is its converging analogue):
     // keep the stream partials of the previous call(s) and divide by the total number of samples at the end
     const bool accumulate = (p->flags & PT_FLAG_ACCUMULATE) != 0;

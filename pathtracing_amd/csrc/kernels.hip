@@ -99,11 +99,13 @@ PT_DEV const ExtArgs &cold()
 #endif
 PT_DEV uint32_t slot_stream(uint32_t slot, const FrameParams &fp)
 {
-    return PT_STREAM_INNER ? (slot >> 6) % fp.streams : slot / fp.slots_per_stream;
+    if (!PT_STREAM_INNER) return slot / fp.slots_per_stream;
+    const uint32_t g = slot >> 6;
+    return g - div_by(g, fp.streams_magic, fp.streams_shift) * fp.streams;
 }
 PT_DEV uint32_t slot_pixel_slot(uint32_t slot, const FrameParams &fp)
 {
-    return PT_STREAM_INNER ? ((((slot >> 6) / fp.streams) << 6) | (slot & 63u)) : slot % fp.slots_per_stream;
+    return PT_STREAM_INNER ? ((div_by(slot >> 6, fp.streams_magic, fp.streams_shift) << 6) | (slot & 63u)) : slot % fp.slots_per_stream;
 }
 PT_DEV size_t slot_of(uint32_t pixel_slot, uint32_t stream, uint32_t streams, uint32_t slots_per_stream)
 {
@@ -119,7 +121,9 @@ PT_DEV size_t slot_of(uint32_t pixel_slot, uint32_t stream, uint32_t streams, ui
 #endif
 PT_DEV void block_pos(const PathState &ps, uint32_t &shard, uint32_t &bx, uint32_t &nbx)
 {
-    if (PT_SHARD_FASTEST) { shard = blockIdx.x % ps.shard_count + ps.shard_base; bx = blockIdx.x / ps.shard_count; nbx = gridDim.x / ps.shard_count; }
+    // shard_count is a power of two (kShards / loops): mask and shift, not a division per wave
+    const uint32_t sh = 31u - (uint32_t)__builtin_clz(ps.shard_count);
+    if (PT_SHARD_FASTEST) { shard = (blockIdx.x & (ps.shard_count - 1u)) + ps.shard_base; bx = blockIdx.x >> sh; nbx = gridDim.x >> sh; }
     else { shard = blockIdx.y + ps.shard_base; bx = blockIdx.x; nbx = gridDim.x; }
 }
 static inline dim3 shard_grid(uint32_t blocks, uint32_t shard_count)
@@ -133,7 +137,7 @@ PT_DEV bool slot_pixel(uint32_t slot_all, const FrameParams &fp, uint32_t &x, ui
     const uint32_t tl = slot >> (2 * kTileShift), inner = slot & (kTilePixels - 1);
     const uint32_t tile = fp.rank + fp.nranks * tl;
     if (tile >= fp.n_tiles) return false;
-    const uint32_t tx = tile % fp.tiles_x, ty = tile / fp.tiles_x;
+    const uint32_t ty = div_by(tile, fp.tiles_x_magic, fp.tiles_x_shift), tx = tile - ty * fp.tiles_x;
     const uint32_t blk = inner >> 6, ln = inner & 63u;
     x = (tx << kTileShift) + ((blk & 7u) << 3) + (ln & 7u);
     y = (ty << kTileShift) + ((blk >> 3) << 3) + (ln >> 3);
@@ -395,7 +399,8 @@ PT_DEV void path_store(const PathState &ps, uint32_t slot, const PathRegs &r)
 // The first sample of a slot's stream: stream k takes the samples s with (sample_offset + s) % K == k, in increasing s (docs/SPEC.md §5).
 PT_DEV uint32_t first_sample(uint32_t slot, const FrameParams &fp)
 {
-    return (slot_stream(slot, fp) + fp.streams - fp.sample_offset % fp.streams) % fp.streams;
+    const uint32_t v = slot_stream(slot, fp) + fp.streams - fp.offset_mod; // in [1, 2 streams)
+    return v >= fp.streams ? v - fp.streams : v;
 }
 // The state a slot starts the frame with: the camera ray of its stream's first sample (slot_pixel(slot) must be on the image).
 PT_DEV void path_init(const DeviceScene &sc, const FrameParams &fp, uint32_t slot, PathRegs &r)

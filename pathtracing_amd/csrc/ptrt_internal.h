@@ -122,7 +122,23 @@ struct FrameParams {
     uint32_t streams;          // K sample streams per pixel (docs/SPEC.md §5); slot <-> (pixel slot, stream): kernels.hip slot_of()
     uint32_t slots_per_stream; // pixel slots of this rank (tiles_per_rank * 4096)
     uint32_t accumulate;       // PT_FLAG_ACCUMULATE: keep the partial sums of the previous frame(s)
+    // Division by `streams` and by `tiles_x` (slot -> pixel, once per regenerated path) as multiply-high + shift: a 32-bit division by a
+    // run-time value is ~22 instructions, five of them quarter-rate integer multiplies, and the regeneration code runs in practically
+    // every bounce of every wave. q = umulhi(n, magic) >> shift is exact for n < 2^31 (magic = ceil(2^(31 + l) / d), shift = l - 1,
+    // l = ceil(log2 d)); magic 0 stands for d == 1. div_magic() below makes the pair on the host.
+    uint32_t streams_magic, streams_shift, tiles_x_magic, tiles_x_shift;
+    uint32_t offset_mod;       // sample_offset % streams
 };
+inline void div_magic(uint32_t d, uint32_t &magic, uint32_t &shift)
+{
+    if (d <= 1u) { magic = 0u; shift = 0u; return; }
+    uint32_t l = 0; while ((1ull << l) < d) ++l;
+    magic = (uint32_t)(((1ull << (31u + l)) + d - 1u) / d); shift = l - 1u;
+}
+inline __host__ __device__ uint32_t div_by(uint32_t n, uint32_t magic, uint32_t shift)
+{
+    return magic ? (uint32_t)(((uint64_t)n * magic) >> 32) >> shift : n; // the high half of a 32 x 32 multiply: v_mul_hi_u32 on the device
+}
 
 // kernel launchers (kernels.hip). All enqueue on `s` and return the launch error.
 // `shard_bound` = upper bound of any shard's queue length for this launch.
