@@ -136,7 +136,7 @@ struct pt_scene {
     mutable double rate_simple = 0.0, rate_packed = 0.0; // rays per ms of whole frames run on one kernel (frames too short to probe inside)
     mutable uint32_t probe_misses = 0;   // warm frames that neither decided nor fed the decision (too few rays to time): after three the scene
                                          // settles on the one-ray-per-lane kernel instead of staying in probe mode (one loop, no finish mode) for good
-    DevBuf<uint32_t> d_sph_mat;
+    DevBuf<uint2> d_sph_mat;
     DeviceScene ds{};
 };
 
@@ -509,7 +509,12 @@ pt_status pt_scene_commit(pt_scene *s, uint32_t bvh_width)
     HIP_TRY(c, s->d_mats.ensure((size_t)nm * 3));
     if (ns) {
         HIP_TRY(c, hipMemcpy(s->d_spheres.p, s->spheres.data(), (size_t)ns * 16, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(s->d_sph_mat.p, s->sph_mat.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
+        std::vector<uint2> mi(ns);
+        for (uint32_t i = 0; i < ns; ++i) { // material id + 1.0f / r (IEEE single division: the value docs/SPEC.md §5 has the shading step compute)
+            const float inv_r = 1.0f / s->spheres[(size_t)i * 4 + 3];
+            mi[i].x = s->sph_mat[i]; std::memcpy(&mi[i].y, &inv_r, 4);
+        }
+        HIP_TRY(c, hipMemcpy(s->d_sph_mat.p, mi.data(), (size_t)ns * sizeof(uint2), hipMemcpyHostToDevice));
     }
     if (nm) HIP_TRY(c, hipMemcpy(s->d_mats.p, s->mats.data(), (size_t)nm * sizeof(pt_material), hipMemcpyHostToDevice));
     lap("upload nodes + rest");

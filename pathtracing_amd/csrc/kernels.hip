@@ -493,9 +493,10 @@ PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FramePar
         } else {
             const uint32_t j = ref - sc.n_tris;
             const float4 s = sc.spheres[j];
-            const float ir = 1.0f / s.w;
+            const uint2 mi = sc.sph_mat[j];
+            const float ir = __uint_as_float(mi.y); // 1.0f / s.w, correctly rounded on the host exactly as the division here would be
             ng = v3((P.x - s.x) * ir, (P.y - s.y) * ir, (P.z - s.z) * ir);
-            mat = sc.sph_mat[j];
+            mat = mi.x;
         }
         const bool front = dot(ng, d) < 0.0f;
         const V3 n = front ? ng : neg(ng);

@@ -78,7 +78,7 @@ struct DeviceScene {
     const float4 *tris;    // 4 rows (one 64-B line) per triangle, blob order: v0|orig_id, e1|material, e2|0, then the
                            // shading row normalize(cross(e1,e2))|material
     const float4 *spheres; // cx,cy,cz,r
-    const uint32_t *sph_mat;
+    const uint2 *sph_mat;  // per sphere: material id, bits of 1.0f / r (the IEEE quotient, made once at commit: the shading step's own division gone)
     const float4 *mats;    // 3 rows per material (48 B pt_material)
     uint32_t n_nodes, n_tris, n_spheres, n_mats;
     float sky[3];
