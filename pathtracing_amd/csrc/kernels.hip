@@ -500,7 +500,13 @@ PT_DEV bool shade_one(const DeviceScene &sc, const PathState &ps, const FramePar
         }
         const bool front = dot(ng, d) < 0.0f;
         const V3 n = front ? ng : neg(ng);
-        const float4 m0 = sc.mats[(size_t)mat * 3], m1 = sc.mats[(size_t)mat * 3 + 1], m2 = sc.mats[(size_t)mat * 3 + 2];
+        float4 m0 = sc.mats[(size_t)mat * 3], m1 = sc.mats[(size_t)mat * 3 + 1];
+        const float4 m2 = sc.mats[(size_t)mat * 3 + 2];
+#ifndef PT_EXP_NO_MATPAIR
+        // Both rows are requested before either is looked at: left alone, the compiler sinks the second load behind the test of the
+        // first row's kind — one more dependent round trip in a step that already chains hit record -> material
+        asm volatile("" : "+v"(m0.x), "+v"(m1.x));
+#endif
         const V3 alb = v3(m0.y, m0.z, m0.w), emi = xyz(m1);
         const uint32_t kind = __float_as_uint(m0.x);
         if (MODE == SHADE_QUEUE && kind != (uint32_t)PT_LAMBERT) { defer = 1u + kind; return false; } // shaded by k_shade<SHADE_BUCKETS>
