@@ -273,9 +273,16 @@ def test_4k_frame_and_full_hd_soup(P, pto, renderer):
     """BASELINE configs[4] frame size (3840x2160, 1M-triangle Cornell) and configs[2] (1M-triangle soup, 1080p) at 1 spp,
     8 streams allocated: the largest slot spaces the benchmark configurations use, against the oracle."""
     sd = P.make_scene(P.native.PT_SCENE_CORNELL_TESS, 1 << 20, 0x5EED0001, 3840, 2160)
-    img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(3840, 2160, spp=1, max_depth=8, streams=8), 0)
+    p4k = P.make_params(3840, 2160, spp=1, max_depth=8, streams=8)
+    img, st, ref, ost = run_both(P, pto, renderer, sd, p4k, 0)
     assert_parity(img, st, ref, ost)
     assert st.paths == 3840 * 2160 and (img[..., 3] == 1.0).all()
+    # configs[4]'s partition exactly — the 4K frame's 2,040 tiles over EIGHT ranks, gathered and un-tiled through pt_comm — as far as one
+    # GPU can take it (virtual ranks): the assembled frame is the oracle's frame, every rank traced its share
+    with P.Comm([renderer] * 8) as comm:
+        stats = comm.Render(p4k)
+        assert sum(s.rays for s in stats) == ost.rays and min(s.rays for s in stats) > 0.1 * ost.rays
+        assert np.array_equal(renderer.ReadFramebuffer(), ref)
     sd = P.make_scene(P.native.PT_SCENE_TRIANGLE_SOUP, 1 << 20, 0x5EED0001, 1920, 1080)
     img, st, ref, ost = run_both(P, pto, renderer, sd, P.make_params(1920, 1080, spp=1, max_depth=8, streams=8), 0)
     assert_parity(img, st, ref, ost)
