@@ -208,7 +208,7 @@ def main():
         gms = [t[2] / args.steps for t in per_rank]
         ranks = {"wall_s": [round(t[0], 4) for t in per_rank], "rays_per_frame": [int(t[1] / args.steps) for t in per_rank],
                  "gpu_ms_per_frame": [round(g, 3) for g in gms], "gpu_ms_max_over_mean": round(max(gms) / (sum(gms) / len(gms)), 4)}
-        pmc, status = load_pmc("tess", [args.scene, args.tris, W, H, args.spp, args.max_depth, args.streams, int(info.width)], kernel_choice)
+        pmc, status = load_pmc("tess", [args.scene, args.tris, W, H, args.spp, args.max_depth, args.streams, int(info.width), int(info.n_nodes)], kernel_choice)
         if pmc and args.scene == "cornell_tess":
             bpr = pmc["hbm_bytes_per_launch"] / pmc["rays_per_launch"]
             gbs = [bpr * t[1] / (t[2] * 1e-3) / 1e9 for t in per_rank]
@@ -223,7 +223,7 @@ def main():
     # ---- roofline of the dominant kernel (untimed extra frames)
     if single and not args.no_roofline:
         pmc_name = {"cornell_tess": "tess", "cornell": "cornell", "cornell_glass": "glass", "soup": "soup"}[args.scene] + ("4k" if (W, H) == (3840, 2160) else "")
-        key = [args.scene, args.tris if args.scene in ("cornell_tess", "soup") else 0, W, H, args.spp, args.max_depth, args.streams, int(info.width)]
+        key = [args.scene, args.tris if args.scene in ("cornell_tess", "soup") else 0, W, H, args.spp, args.max_depth, args.streams, int(info.width), int(info.n_nodes)]
         out["roofline"] = kernel_roofline(P, r, mk, info, kernel_choice, pmc_name, key)
         out["roofline"]["timed_region"] = {"loops": int(r.GetTuning().loops) or 2, "frame_ms": out["ms_per_step"],
                                            "note": "the timed frames run the library default: two independent shard-group loops on two streams, "
@@ -285,7 +285,7 @@ def load_pmc(name, key, kernel_choice):
     except (OSError, ValueError):
         return None, f"no counter profile {os.path.relpath(path, ROOT)}"
     k, want = j.get("workload_key") or [], list(key)
-    if len(k) != 8 or k[:4] + k[5:] != want[:4] + want[5:]:
+    if len(k) != 9 or k[:4] + k[5:] != want[:4] + want[5:]:  # scene, detail, size, depth, streams, node layout and node count (the tree itself); not spp
         return None, f"counter profile is of another workload ({k} vs {want})"
     if not (j.get("kernel", "") == kernel_choice or j.get("kernel", "").startswith(kernel_choice + "<")):
         return None, f"counter profile is of {j.get('kernel')}, this run used {kernel_choice}"
@@ -415,7 +415,7 @@ def other_configs(P, r, W, H, want_roofline):
 
             def mkr(spp=spp_r, flags=0, mk=mk, kflag=kflag):
                 return mk(spp=spp, flags=flags | kflag)
-            key = [scene_key, detail, w, h, spp_r, depth, 8, int(info.width)]
+            key = [scene_key, detail, w, h, spp_r, depth, 8, int(info.width), int(info.n_nodes)]
             e["roofline"] = kernel_roofline(P, r, mkr, info, e["extend_kernel"], pmc_name, key)
         res.append(e)
     # the reference's own kernel (Test.hlsl:1-40 -> k_reference_sphere): one float4 + one RGBA8 store per pixel, 20 B/pixel
@@ -433,7 +433,7 @@ def other_configs(P, r, W, H, want_roofline):
                       "achieved_is": "algorithmic bytes written (20 B/pixel: float4 + RGBA8, Test.hlsl:39) / mean kernel duration (HIP events); a 41 MB "
                                      "frame is a ~10 us kernel: launch ramp and tail, not bandwidth, set its duration",
                       "traffic": None}}
-    pmc, status = load_pmc("sphere", ["sphere", 0, W, H, 1, 0, 0, 0], "k_reference_sphere")
+    pmc, status = load_pmc("sphere", ["sphere", 0, W, H, 1, 0, 0, 0, 0], "k_reference_sphere")
     if pmc:
         e["roofline"]["traffic"] = {"bytes_per_launch": pmc["hbm_bytes_per_launch"], "source": pmc["source"]}
     e["roofline"]["counters"] = status

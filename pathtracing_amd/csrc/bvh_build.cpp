@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <thread>
 
@@ -187,12 +188,50 @@ void emit_blob(const std::vector<Tmp> &tn, int32_t root, const std::vector<uint3
     struct Pending { int32_t kids[8]; int nk; }; // width <= 8; kids[c] < 0: empty slot (octant_slots leaves holes anywhere)
     std::vector<Pending> pend;
     pend.reserve(tn.size());
+    // Which binary nodes become the children of a wide node: chosen by the SAH-optimal dynamic programme of Ylitie, Karras & Laine
+    // (HPG 2017, §3.1) — round 1-2 opened the child of largest area until the node was full (PTRT_COLLAPSE=area keeps that for
+    // comparison: 1M-triangle Cornell 7.60 -> 7.48 node visits per ray with 16 % fewer nodes, soup 28.92 -> 28.72).
+    // cost[n][i-1] = least SAH cost of the subtree under binary node n when it may take up to i child slots of its parent (i = 1: n is
+    // itself a node, or a leaf — the binary builder's leaves stay leaves, so the triangle term is a constant of the tree).
+    const char *collapse_env = getenv("PTRT_COLLAPSE");
+    const bool dp = !(collapse_env && std::strcmp(collapse_env, "area") == 0);
+    const float c_tri = 0.6f; // a triangle test relative to a node visit
+    std::vector<float> cost;
+    auto C = [&](int32_t n, uint32_t i) -> float & { return cost[(size_t)n * width + (i - 1)]; };
+    auto best_split = [&](int32_t n, uint32_t j, uint32_t &kbest) { // least cost of giving j >= 2 slots to the two children of n
+        float best = kInf; kbest = 1;
+        for (uint32_t k = 1; k < j; ++k) { const float v = C(tn[n].left, k) + C(tn[n].right, j - k); if (v < best) { best = v; kbest = k; } }
+        return best;
+    };
+    if (dp) {
+        cost.assign(tn.size() * width, 0.f);
+        for (int64_t n = (int64_t)tn.size() - 1; n >= 0; --n) { // children have larger indices than their parents
+            const float a = tn[n].box.area() / std::max(tn[root].box.area(), 1e-30f);
+            if (tn[n].count) { for (uint32_t i = 1; i <= width; ++i) C((int32_t)n, i) = a * c_tri * (float)tn[n].count; continue; }
+            if (tn[n].left < 0 || tn[n].right < 0) continue; // (placeholder of the parallel build: never reachable)
+            uint32_t k;
+            C((int32_t)n, 1) = a + best_split((int32_t)n, width, k);
+            for (uint32_t i = 2; i <= width; ++i) C((int32_t)n, i) = std::min(best_split((int32_t)n, i, k), C((int32_t)n, i - 1));
+        }
+    }
+    std::function<void(int32_t, uint32_t, Pending &)> gather = [&](int32_t n, uint32_t j, Pending &p) { // the <= j roots binary node n contributes
+        if (tn[n].count || j == 1) { p.kids[p.nk++] = n; return; }
+        uint32_t k;
+        const float split = best_split(n, j, k);
+        if (C(n, j - 1) <= split) { gather(n, j - 1, p); return; }
+        gather(tn[n].left, k, p); gather(tn[n].right, j - k, p);
+    };
     auto expand = [&](int32_t t) { // children of the output node made from tmp node t
         Pending p; p.nk = 0;
         for (int i = 0; i < 8; ++i) p.kids[i] = -1;
         if (tn[t].count) { p.kids[p.nk++] = t; return p; } // (root is a leaf) single child
+        if (dp) {
+            uint32_t k; (void)best_split(t, width, k);
+            gather(tn[t].left, k, p); gather(tn[t].right, width - k, p);
+        } else {
         p.kids[p.nk++] = tn[t].left; p.kids[p.nk++] = tn[t].right;
-        while (p.nk < (int)width) {
+        }
+        while (!dp && p.nk < (int)width) {
             int best = -1; float ba = -1.f;
             for (int i = 0; i < p.nk; ++i)
                 if (!tn[p.kids[i]].count) { const float a = tn[p.kids[i]].box.area(); if (a > ba) { ba = a; best = i; } }

@@ -24,7 +24,7 @@ def test_committed_counter_profiles_belong_to_the_current_kernels():
     for f in files:
         j = json.load(open(f))
         assert j["source_sha256"] == b.source_hash(), f"{os.path.relpath(f, ROOT)} was taken on other kernel sources: re-run the profiling session"
-        assert j["per_launch"] and j["hbm_bytes_per_launch"] > 0 and len(j["workload_key"]) == 8
+        assert j["per_launch"] and j["hbm_bytes_per_launch"] > 0 and len(j["workload_key"]) == 9
 
 
 def test_counter_profiles_are_dropped_when_anything_differs(monkeypatch):
@@ -38,6 +38,8 @@ def test_counter_profiles_are_dropped_when_anything_differs(monkeypatch):
     other_size = list(key); other_size[2] = 3840
     assert b.load_pmc("tess", other_size, kern)[0] is None
     assert b.load_pmc("tess", key, "k_extend_packed")[0] is None
+    other_tree = list(key); other_tree[8] += 1            # another builder, another tree: other counters per ray
+    assert b.load_pmc("tess", other_tree, kern)[0] is None
     assert b.load_pmc("no_such_profile", key, kern)[0] is None
     monkeypatch.setattr(b, "source_hash", lambda: "0" * 64)  # the kernels changed since the counters were taken
     pmc, why = b.load_pmc("tess", key, kern)

@@ -24,7 +24,7 @@ else:
 for _ in range(frames):
     st = r.Render(0.0)
 import json
-key = ["sphere", 0, W, H, 1, 0, 0, 0] if scene == "sphere" else [{"tess": "cornell_tess", "glass": "cornell_glass"}.get(scene, scene), kinds[scene][1], W, H, spp, depth, 8, int(r.BvhInfo().width)]
+key = ["sphere", 0, W, H, 1, 0, 0, 0, 0] if scene == "sphere" else [{"tess": "cornell_tess", "glass": "cornell_glass"}.get(scene, scene), kinds[scene][1], W, H, spp, depth, 8, int(r.BvhInfo().width), int(r.BvhInfo().n_nodes)]
 print(f"{scene} {W}x{H} {spp} spp: {st.gpu_ms:.3f} ms, {st.rays} rays, {st.iterations} launches, kernel {int(st.reserved[0])}", flush=True)
 print("workload_key " + json.dumps(key), flush=True)
 r.Dispose()
