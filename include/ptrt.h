@@ -152,8 +152,8 @@ typedef struct {
 
 /* Scheduling knobs of a context (none changes a pixel; tests/test_gpu_parity.py holds every setting to the same frame). Read the
  * current values with pt_context_get_tuning, change what you want, write them back. The library reads no environment variables for
- * these (developer aids aside: the stderr diagnostics PTRT_TRACE / PTRT_TIMING, and PTRT_NODE_ORDER / PTRT_UNIFIED, which give the
- * same tree another memory order for the layout experiments of DESIGN.md). */
+ * these (developer aids aside: the stderr diagnostics PTRT_TRACE / PTRT_TIMING, and PTRT_NODE_ORDER / PTRT_UNIFIED / PTRT_COLLAPSE, which give
+ * the same tree another memory order, or collapse it to wide nodes by the old rule, for the builder experiments of DESIGN.md). */
 typedef struct {
     uint32_t bounces;       /* path vertices a lane advances per launch of the fused extend kernels, 1..64; 0 (default) = 3/4 max_depth - 2
                                clamped to [4, 12] for the one-ray-per-lane kernel, 64 for the lane-packing one */
